@@ -1,0 +1,118 @@
+/* chmc.h -- C ABI of the MI355X-native batched constrained-HMC leapfrog library (libchmc_hip.so).
+ *
+ * The reference (thiery-lab/manifold-mcmc-for-diffusions) has no FFI of its own: its hot path is a set of
+ * JAX-jitted closures behind Mici's duck-typed System / Integrator / projection-solver protocol.  Each entry
+ * point below therefore replaces one of those closures / methods (file:line relative to the reference tree),
+ * batched over `num_chains` independent chains.  All arrays are fp64, C-contiguous, chain-major; host
+ * pointers unless the name ends in `_device`.  The caller owns its buffers for the duration of a call; the
+ * context owns all device memory.  A context is bound to one device / one stream and is not re-entrant.
+ *
+ * Return value: 0 on success, <0 on API misuse or a HIP error (text via chmc_last_error()).  Numerical
+ * outcomes are per-chain status codes, never a non-zero return.
+ */
+#ifndef CHMC_H
+#define CHMC_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* model ids: which `forward_func / generate_z / generate_x_0 / obs_func` set is compiled in
+ * (sde/example_models/fhn.py, sde/example_models/sir.py) */
+#define CHMC_MODEL_FHN 0
+#define CHMC_MODEL_SIR 1
+
+/* per-chain status of a projection / leapfrog step (exception classes of the reference):
+ *   0 ok
+ *   1 ConvergenceError "did not converge"           sde/mici_extensions.py:1398-1402, 1472-1476
+ *   2 ConvergenceError "diverged" (|c| > dtol, NaN) sde/mici_extensions.py:1393-1397, 1467-1471
+ *   3 NonReversibleStepError                        mici ConstrainedLeapfrogIntegrator._step_b
+ *  -1 chain was not active in the call */
+#define CHMC_OK 0
+#define CHMC_NOT_CONVERGED 1
+#define CHMC_DIVERGED 2
+#define CHMC_NON_REVERSIBLE 3
+#define CHMC_INACTIVE (-1)
+
+typedef struct chmc_ctx chmc_ctx;
+
+/* Arguments of ConditionedDiffusionConstrainedSystem.__init__ (sde/mici_extensions.py:211-228) that can cross
+ * a C ABI; the model callables are replaced by `model`.  Identity metric only. */
+typedef struct chmc_config {
+  int model;                  /* CHMC_MODEL_* */
+  int num_obs;                /* T = y_seq.shape[0] (dim_y = 1) */
+  int num_steps_per_obs;      /* S */
+  int num_obs_per_subseq;     /* R; 0 or >= T: no partitioning (:321-324) */
+  int noisy;                  /* generate_sigma is not None (:353) */
+  int use_gaussian_splitting; /* :273-278 */
+  int num_chains;             /* B */
+  int device;                 /* HIP device ordinal */
+  double obs_interval;
+  double sigma;               /* fixed observation-noise std (generate_sigma given as a Number, :354-358) */
+  const double* y_seq;        /* [T] */
+} chmc_config;
+
+int chmc_create(const chmc_config* cfg, chmc_ctx** out);
+void chmc_destroy(chmc_ctx* ctx);
+const char* chmc_last_error(void);
+const char* chmc_backend(void); /* "hip:gfx950" */
+
+/* dims[16] = {B, Q, NV, U, X, T, S, num_partition, RM, Kmax, C(part 0), C(part 1), K(part 0), K(part 1), V, V0} */
+int chmc_get_dims(const chmc_ctx* ctx, int* dims);
+/* blocks of a partition (sde/mici_extensions.py:321-351): 12 ints per block
+ * {obs0, nobs, first, last, row0, nrows, ny, col0, ncols, step0, nsteps, 0} */
+int chmc_get_blocks(const chmc_ctx* ctx, int partition, int* out);
+
+/* ---- chain state: ConditionedDiffusionHamiltonianState (sde/mici_extensions.py:1285-1320) ------------- */
+/* Sets pos [B][Q], mom [B][Q] (may be NULL), x_obs_seq [B][T][X], partition, and evaluates everything the
+ * reference caches on a state (jacob_constr_blocks, chol_gram_blocks, log_det_sqrt_gram, grad_log_det_sqrt_gram,
+ * :1151-1184). */
+int chmc_set_state(chmc_ctx* ctx, const double* q, const double* p, const double* x_obs_seq, int partition);
+int chmc_get_state(chmc_ctx* ctx, double* q, double* p, double* x_obs_seq, int* partition);
+int chmc_set_momentum(chmc_ctx* ctx, const double* p);
+int chmc_get_state_device(chmc_ctx* ctx, void* q_dev, void* p_dev);  /* device-to-device copies */
+int chmc_set_momentum_device(chmc_ctx* ctx, const void* p_dev);
+/* system.update_x_obs_seq(state) (:1240-1241, :384-397) */
+int chmc_update_x_obs_seq(chmc_ctx* ctx);
+/* SwitchPartitionTransition.sample (:1279-1282): partition = (partition + 1) % num_partition, update x_obs_seq,
+ * re-evaluate the state caches */
+int chmc_switch_partition(chmc_ctx* ctx);
+
+/* ---- per-op entry points, evaluated at the current state ------------------------------------------------ */
+int chmc_constr(chmc_ctx* ctx, double* c);                                  /* :473-519, :1151-1155  [B][C] */
+/* :521-624, :1157-1161.  dc_du [B][C][U]; dc_dv [B][RM][NV] row-slot layout (slot i = row i of the block that
+ * owns the column); dc/dn is sigma on observation rows (:601-608). */
+int chmc_jacob_constr_blocks(chmc_ctx* ctx, double* dc_du, double* dc_dv);
+int chmc_chol_gram_blocks(chmc_ctx* ctx, double* chol_C, double* chol_D);   /* :626-687  [B][U][U], [B][K][RM][RM] */
+int chmc_log_det_sqrt_gram(chmc_ctx* ctx, double* out);                     /* :800-820, :1169-1171  [B] */
+int chmc_grad_log_det_sqrt_gram(chmc_ctx* ctx, double* grad);               /* :1143-1146, :1173-1184  [B][Q] */
+int chmc_lmult_by_jacob_constr(chmc_ctx* ctx, const double* vct, double* out);   /* :822-877  [B][Q] -> [B][C] */
+int chmc_rmult_by_jacob_constr(chmc_ctx* ctx, const double* vct, double* out);   /* :879-913  [B][C] -> [B][Q] */
+int chmc_lmult_by_inv_gram(chmc_ctx* ctx, const double* vct, double* out);       /* :915-942  [B][C] -> [B][C] */
+int chmc_normal_space_component(chmc_ctx* ctx, const double* vct, double* out);  /* :983-993, :1243-1250 */
+int chmc_project_onto_cotangent_space(chmc_ctx* ctx);  /* :1252-1254, in place on the state's momentum */
+int chmc_hamiltonian(chmc_ctx* ctx, double* h);        /* :1186-1202  [B][3] = {h1 + h2, q.q/2, p.p/2} */
+
+/* Projection solvers (newton != 0: newton_projection :1065-1135 with its host wrapper :1405-1476;
+ * newton == 0: quasi_newton_projection :999-1063 / :1323-1402).  Projects the points q [B][Q] onto the manifold
+ * along the rows of the constraint Jacobian at the CURRENT state (= `state_prev` of the reference).
+ * Outputs: q_out [B][Q]; mu_out [B][Q] = mu/dt (mu/sin dt with Gaussian splitting); iters, norm_dq, err, status [B].
+ * The state itself is not modified. */
+int chmc_project(chmc_ctx* ctx, int newton, const double* q, const double* dt, double constraint_tol,
+                 double position_tol, double divergence_tol, int max_iters, double* q_out, double* mu_out,
+                 int* iters, double* norm_dq, double* err, int* status);
+
+/* One ConstrainedLeapfrogIntegrator.step per chain (mici 0.1.10, n_inner_step == 1): A(dt/2) B(dt) A(dt/2) with
+ * forward projection, reverse projection and reversibility check.  dt [B] = state.dir * step_size; active [B]
+ * (NULL: all).  A chain whose step fails keeps its state (Mici discards the partial step). */
+int chmc_leapfrog_step(chmc_ctx* ctx, const double* dt, const int* active, int n_inner_step, int newton,
+                       double constraint_tol, double position_tol, double divergence_tol, int max_iters,
+                       double reverse_check_tol, int* status, int* iters_fwd, int* iters_bwd, double* rev_err);
+
+/* evaluation counters since creation: {constr, jacob_constr_blocks, lu_jacob_product_blocks, chol_gram_blocks,
+ * grad_log_det_sqrt_gram, leapfrog_step calls, newton iteration launches, 0} (cf. _call_counts, :1451-1461) */
+int chmc_get_counters(const chmc_ctx* ctx, long long* out8);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,203 @@
+"""Thin NumPy-facing wrapper of one `chmc_ctx` (include/chmc.h): a batch of B chains resident on one MI355X.
+
+This is the level bench.py and the multi-GPU driver work at; the Mici-style classes in system.py /
+integrators.py sit on top of it.
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+from ._lib import ChmcConfig, as_c, ptr, iptr, check
+
+MODEL_IDS = {"fhn": 0, "sir": 1}
+STATUS_NAMES = {0: "ok", 1: "not_converged", 2: "diverged", 3: "non_reversible", -1: "inactive"}
+
+
+class ChmcContext:
+    def __init__(self, model, obs_interval, num_steps_per_obs, num_obs_per_subseq, y_seq, sigma=None,
+                 use_gaussian_splitting=False, num_chains=1, device=0):
+        L = _lib.lib()
+        self.L = L
+        y = as_c(np.asarray(y_seq).reshape(-1))
+        self._y = y
+        cfg = ChmcConfig(
+            model=MODEL_IDS[model] if isinstance(model, str) else int(model), num_obs=len(y),
+            num_steps_per_obs=int(num_steps_per_obs),
+            num_obs_per_subseq=0 if num_obs_per_subseq is None else int(num_obs_per_subseq),
+            noisy=int(sigma is not None), use_gaussian_splitting=int(bool(use_gaussian_splitting)),
+            num_chains=int(num_chains), device=int(device), obs_interval=float(obs_interval),
+            sigma=0.0 if sigma is None else float(sigma), y_seq=ptr(y))
+        h = C.c_void_p()
+        check(L.chmc_create(C.byref(cfg), C.byref(h)), "chmc_create")
+        self.h = h
+        d = np.zeros(16, dtype=np.int32)
+        check(L.chmc_get_dims(h, iptr(d)), "chmc_get_dims")
+        (self.B, self.Q, self.NV, self.U, self.X, self.T, self.S, self.num_partition, self.RM, self.Kmax) = map(int, d[:10])
+        self.C = [int(d[10]), int(d[11])][: self.num_partition]
+        self.K = [int(d[12]), int(d[13])][: self.num_partition]
+        self.V, self.V0 = int(d[14]), int(d[15])
+        self.noisy = sigma is not None
+        self.sigma = sigma
+        self.partition = 0
+        self.blocks = []
+        keys = ("obs0", "nobs", "first", "last", "row0", "nrows", "ny", "col0", "ncols", "step0", "nsteps", "_")
+        for p in range(self.num_partition):
+            raw = np.zeros(self.K[p] * 12, dtype=np.int32)
+            check(L.chmc_get_blocks(h, p, iptr(raw)), "chmc_get_blocks")
+            self.blocks.append([dict(zip(keys, map(int, raw[12 * b:12 * b + 12]))) for b in range(self.K[p])])
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.chmc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- state
+    def _bq(self, a, name):
+        a = as_c(a)
+        if a.shape != (self.B, self.Q):
+            raise ValueError(f"{name} must have shape ({self.B}, {self.Q}), got {a.shape}")
+        return a
+
+    def set_state(self, q, p, x_obs_seq, partition=0):
+        q = self._bq(q, "q")
+        p = None if p is None else self._bq(p, "p")
+        xo = as_c(x_obs_seq)
+        if xo.shape != (self.B, self.T, self.X):
+            raise ValueError(f"x_obs_seq must have shape ({self.B}, {self.T}, {self.X})")
+        check(self.L.chmc_set_state(self.h, ptr(q), ptr(p), ptr(xo), int(partition)), "chmc_set_state")
+        self.partition = int(partition)
+
+    def get_state(self, want_p=True, want_x_obs=True):
+        q = np.empty((self.B, self.Q))
+        p = np.empty((self.B, self.Q)) if want_p else None
+        xo = np.empty((self.B, self.T, self.X)) if want_x_obs else None
+        part = C.c_int(0)
+        check(self.L.chmc_get_state(self.h, ptr(q), ptr(p), ptr(xo), C.byref(part)), "chmc_get_state")
+        return q, p, xo, part.value
+
+    def set_momentum(self, p):
+        p = self._bq(p, "p")
+        check(self.L.chmc_set_momentum(self.h, ptr(p)), "chmc_set_momentum")
+
+    def get_state_device(self, q_dev_ptr, p_dev_ptr):
+        check(self.L.chmc_get_state_device(self.h, C.c_void_p(q_dev_ptr or 0), C.c_void_p(p_dev_ptr or 0)),
+              "chmc_get_state_device")
+
+    def set_momentum_device(self, p_dev_ptr):
+        check(self.L.chmc_set_momentum_device(self.h, C.c_void_p(p_dev_ptr)), "chmc_set_momentum_device")
+
+    def update_x_obs_seq(self):
+        check(self.L.chmc_update_x_obs_seq(self.h), "chmc_update_x_obs_seq")
+
+    def switch_partition(self):
+        check(self.L.chmc_switch_partition(self.h), "chmc_switch_partition")
+        self.partition = (self.partition + 1) % self.num_partition
+
+    # ---- per-op
+    @property
+    def dim_c(self):
+        return self.C[self.partition]
+
+    @property
+    def num_blocks(self):
+        return self.K[self.partition]
+
+    def constr(self):
+        c = np.empty((self.B, self.dim_c))
+        check(self.L.chmc_constr(self.h, ptr(c)), "chmc_constr")
+        return c
+
+    def jacob_constr_blocks(self, want_dv=True):
+        du = np.empty((self.B, self.dim_c, self.U))
+        dv = np.empty((self.B, self.RM, self.NV)) if want_dv else None
+        check(self.L.chmc_jacob_constr_blocks(self.h, ptr(du), ptr(dv)), "chmc_jacob_constr_blocks")
+        return du, dv
+
+    def chol_gram_blocks(self):
+        cC = np.empty((self.B, self.U, self.U))
+        cD = np.empty((self.B, self.num_blocks, self.RM, self.RM))
+        check(self.L.chmc_chol_gram_blocks(self.h, ptr(cC), ptr(cD)), "chmc_chol_gram_blocks")
+        return cC, cD
+
+    def log_det_sqrt_gram(self):
+        out = np.empty(self.B)
+        check(self.L.chmc_log_det_sqrt_gram(self.h, ptr(out)), "chmc_log_det_sqrt_gram")
+        return out
+
+    def grad_log_det_sqrt_gram(self):
+        g = np.empty((self.B, self.Q))
+        check(self.L.chmc_grad_log_det_sqrt_gram(self.h, ptr(g)), "chmc_grad_log_det_sqrt_gram")
+        return g
+
+    def lmult_by_jacob_constr(self, vct):
+        vct = self._bq(vct, "vct")
+        out = np.empty((self.B, self.dim_c))
+        check(self.L.chmc_lmult_by_jacob_constr(self.h, ptr(vct), ptr(out)), "chmc_lmult_by_jacob_constr")
+        return out
+
+    def _bc(self, a, name):
+        a = as_c(a)
+        if a.shape != (self.B, self.dim_c):
+            raise ValueError(f"{name} must have shape ({self.B}, {self.dim_c}), got {a.shape}")
+        return a
+
+    def rmult_by_jacob_constr(self, lam):
+        lam = self._bc(lam, "vct")
+        out = np.empty((self.B, self.Q))
+        check(self.L.chmc_rmult_by_jacob_constr(self.h, ptr(lam), ptr(out)), "chmc_rmult_by_jacob_constr")
+        return out
+
+    def lmult_by_inv_gram(self, vct):
+        vct = self._bc(vct, "vct")
+        out = np.empty((self.B, self.dim_c))
+        check(self.L.chmc_lmult_by_inv_gram(self.h, ptr(vct), ptr(out)), "chmc_lmult_by_inv_gram")
+        return out
+
+    def normal_space_component(self, vct):
+        vct = self._bq(vct, "vct")
+        out = np.empty((self.B, self.Q))
+        check(self.L.chmc_normal_space_component(self.h, ptr(vct), ptr(out)), "chmc_normal_space_component")
+        return out
+
+    def project_onto_cotangent_space(self):
+        check(self.L.chmc_project_onto_cotangent_space(self.h), "chmc_project_onto_cotangent_space")
+
+    def hamiltonian(self):
+        h = np.empty((self.B, 3))
+        check(self.L.chmc_hamiltonian(self.h, ptr(h)), "chmc_hamiltonian")
+        return h
+
+    def project(self, q, dt, newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10, max_iters=50):
+        q = self._bq(q, "q")
+        dt = as_c(np.broadcast_to(np.asarray(dt, dtype=np.float64), (self.B,)))
+        q_out, mu = np.empty((self.B, self.Q)), np.empty((self.B, self.Q))
+        iters, status = np.zeros(self.B, dtype=np.int32), np.zeros(self.B, dtype=np.int32)
+        ndq, err = np.empty(self.B), np.empty(self.B)
+        check(self.L.chmc_project(self.h, int(newton), ptr(q), ptr(dt), constraint_tol, position_tol, divergence_tol,
+                                  int(max_iters), ptr(q_out), ptr(mu), iptr(iters), ptr(ndq), ptr(err), iptr(status)),
+              "chmc_project")
+        return dict(q=q_out, mu=mu, iters=iters, norm_dq=ndq, err=err, status=status)
+
+    def leapfrog_step(self, dt, active=None, n_inner_step=1, newton=True, constraint_tol=1e-9, position_tol=1e-8,
+                      divergence_tol=1e10, max_iters=50, reverse_check_tol=2e-8):
+        dt = as_c(np.broadcast_to(np.asarray(dt, dtype=np.float64), (self.B,)))
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.int32)
+        status = np.zeros(self.B, dtype=np.int32)
+        itf, itb = np.zeros(self.B, dtype=np.int32), np.zeros(self.B, dtype=np.int32)
+        rev = np.zeros(self.B)
+        check(self.L.chmc_leapfrog_step(self.h, ptr(dt), iptr(act), int(n_inner_step), int(newton), constraint_tol,
+                                        position_tol, divergence_tol, int(max_iters), reverse_check_tol, iptr(status),
+                                        iptr(itf), iptr(itb), ptr(rev)), "chmc_leapfrog_step")
+        return dict(status=status, iters_fwd=itf, iters_bwd=itb, rev_err=rev)
+
+    def counters(self):
+        out = (C.c_longlong * 8)()
+        check(self.L.chmc_get_counters(self.h, out), "chmc_get_counters")
+        keys = ("constr", "jacob_constr_blocks", "lu_jacob_product_blocks", "chol_gram_blocks",
+                "grad_log_det_sqrt_gram", "leapfrog_step", "projection_iterations", "_")
+        return dict(zip(keys, (int(v) for v in out)))

@@ -1,0 +1,1263 @@
+// Device-side work functions of the batched constrained-HMC leapfrog step.
+//
+// Every kernel is a functor with `operator()(int tid)`; the HIP backend (chmc.hip) launches
+// them over a 1-D grid, one work item per lane.  Work items are (chain), (chain, block),
+// (chain, block, row) or (chain, column) -- "block" being one conditionally independent
+// sub-sequence of the observation sequence (sde/mici_extensions.py:321-351, 413-471).
+//
+// Data layout in HBM (B chains, all fp64, chain-major so a chain's state is contiguous):
+//   q, p, grad   [B][Q]            q = [u(U) | v_0(V0) | v_seq(T*S*V) | n(T)]  (:476-484)
+//   traj         [B][T*S+Kmax][X]  per block nsteps+1 states (x_s before step s)
+//   Jv           [B][RM][NV]       "row-slot" Jacobian: slot i holds row i of the block that
+//                                  owns the column, so J^T lambda / J w / Gram builds are
+//                                  unit-stride streams over the v-part of q
+//   JuP, E       [B][Kmax][RM][U]  dc/du rows and D^-1 dc/du, padded to RM rows per block
+//   facD         [B][Kmax][RM][RM] Cholesky factor of D_b, identity-padded
+//   facC, Cinv   [B][U][U]
+// Two state slots (current state / proposal) are selected per chain through `cur[c]`, so
+// accepting a step is a flag flip, not a copy.
+//
+// Reference lines cited as :NNN are sde/mici_extensions.py unless stated otherwise.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+#include "chmc_model.h"
+
+#if defined(__HIPCC__)
+#define CHMC_UNROLL _Pragma("unroll")
+#else
+#define CHMC_UNROLL
+#endif
+
+namespace chmc {
+
+struct BlockDesc {
+  int obs0, nobs, first, last;
+  int row0, nrows, ny;
+  int col0, ncols;
+  int step0, nsteps;
+  int pad_;
+};
+
+struct Sys {
+  int B, T, S, noisy, gaussian;
+  int U, X, V, Z, V0;
+  int Q, NV, K, C, Kmax, RM, TRJ, NCOL;  // NCOL = NV + (noisy ? T : 0)
+  double dl, sigma;
+  const double* y;
+  const double* xobs;  // [B][T][X]
+  const BlockDesc* blk;
+  const int* obs2blk;
+};
+
+struct Slots {
+  double* q[2];
+  double* p[2];
+  double* traj[2];
+  double* JuP[2];
+  double* Jv[2];
+  double* facD[2];
+  double* E[2];
+  double* facC[2];
+  double* Cinv[2];
+  double* ldb[2];
+  double* logdet[2];
+  double* grad[2];
+  int* cur;
+};
+
+struct Work {
+  double* trajw;    // [B][TRJ]      trajectory of the Newton iterate
+  double* cpad;     // [B][Kmax][RM] constraint values, block-padded
+  double* tpad;     // [B][Kmax][RM] D_b^-1 (rhs)_b
+  double* lampad;   // [B][Kmax][RM] multipliers
+  double* Ew;       // [B][Kmax][RM][U] D_b^-1 dc/du (current iterate)
+  double* Cb;       // [B][Kmax][U][U]
+  double* sb;       // [B][Kmax][U]
+  double* mu;       // [B][Q]
+  double* qb;       // [B][Q]        reverse-check iterate
+  double* pb;       // [B][Q]
+  double* vin;      // [B][Q]        generic input vector (per-op API)
+  double* Xd;       // [B][T*S][RM][X] tangents for grad log det
+  double* gup;      // [B][Kmax][U]
+  double* err;      // [B]
+  unsigned long long* ndq;  // [B] bit pattern of max |dq|
+  unsigned long long* rev;  // [B] bit pattern of reverse-check distance
+  double* dt;       // [B]
+  double* part;     // [B][NPART] partial sums
+  int* iters;       // [B]
+  int* nw;          // [B] Newton loop active
+  int* ok;          // [B] chain still good in this step
+  int* status;      // [B]
+  int* nstat;       // [B] status of last projection
+  int* n_active;    // [1]
+};
+
+CHMC_HD inline unsigned long long dbits(double x) {
+  union { double d; unsigned long long u; } c;
+  c.d = x;
+  return c.u;
+}
+CHMC_HD inline double bitsd(unsigned long long u) {
+  union { double d; unsigned long long u; } c;
+  c.u = u;
+  return c.d;
+}
+// max over |x| as a bit pattern: non-negative doubles order like integers and NaN sorts above inf,
+// which reproduces jnp.max(jnp.abs(.)) NaN propagation (:995-997)
+CHMC_HD inline unsigned long long absbits(double x) { return dbits(fabs(x)) & 0x7fffffffffffffffULL; }
+
+#if defined(__HIPCC__)
+__device__ inline void atomic_max_u64(unsigned long long* a, unsigned long long v) { atomicMax(a, v); }
+__device__ inline void atomic_add_i32(int* a, int v) { atomicAdd(a, v); }
+#else
+inline void atomic_max_u64(unsigned long long* a, unsigned long long v) {
+  if (v > *a) *a = v;
+}
+inline void atomic_add_i32(int* a, int v) { *a += v; }
+#endif
+
+// ------------------------------------------------------------------------------------------
+// small dense linear algebra on fixed-size (register) arrays
+template <int N>
+CHMC_HD inline double chol_lower(double* a) {  // in place, returns sum log |diag|
+  double ld = 0.0;
+  CHMC_UNROLL
+  for (int j = 0; j < N; ++j) {
+    double d = a[j * N + j];
+    CHMC_UNROLL
+    for (int k = 0; k < N; ++k)
+      if (k < j) d -= a[j * N + k] * a[j * N + k];
+    d = sqrt(d);
+    a[j * N + j] = d;
+    ld += log(fabs(d));
+    double inv = 1.0 / d;
+    CHMC_UNROLL
+    for (int i = 0; i < N; ++i)
+      if (i > j) {
+        double t = a[i * N + j];
+        CHMC_UNROLL
+        for (int k = 0; k < N; ++k)
+          if (k < j) t -= a[i * N + k] * a[j * N + k];
+        a[i * N + j] = t * inv;
+      }
+    CHMC_UNROLL
+    for (int i = 0; i < N; ++i)
+      if (i < j) a[i * N + j] = 0.0;
+  }
+  return ld;
+}
+template <int N, int NR>
+CHMC_HD inline void cho_solve(const double* L, double* b) {  // b [N][NR] in place
+  CHMC_UNROLL
+  for (int c = 0; c < NR; ++c) {
+    CHMC_UNROLL
+    for (int i = 0; i < N; ++i) {
+      double t = b[i * NR + c];
+      CHMC_UNROLL
+      for (int k = 0; k < N; ++k)
+        if (k < i) t -= L[i * N + k] * b[k * NR + c];
+      b[i * NR + c] = t / L[i * N + i];
+    }
+    CHMC_UNROLL
+    for (int i = N - 1; i >= 0; --i) {
+      double t = b[i * NR + c];
+      CHMC_UNROLL
+      for (int k = 0; k < N; ++k)
+        if (k > i) t -= L[k * N + i] * b[k * NR + c];
+      b[i * NR + c] = t / L[i * N + i];
+    }
+  }
+}
+template <int N>
+CHMC_HD inline void lu_factor(double* a, int* piv) {  // partial pivoting, LAPACK getrf semantics (:745-752)
+  CHMC_UNROLL
+  for (int j = 0; j < N; ++j) {
+    int p = j;
+    double mx = fabs(a[j * N + j]);
+    CHMC_UNROLL
+    for (int i = 0; i < N; ++i)
+      if (i > j) {
+        double v = fabs(a[i * N + j]);
+        if (v > mx) mx = v, p = i;
+      }
+    piv[j] = p;
+    CHMC_UNROLL
+    for (int i = 0; i < N; ++i)
+      if (i > j && i == p) {
+        CHMC_UNROLL
+        for (int k = 0; k < N; ++k) {
+          double t = a[j * N + k];
+          a[j * N + k] = a[i * N + k];
+          a[i * N + k] = t;
+        }
+      }
+    double inv = 1.0 / a[j * N + j];
+    CHMC_UNROLL
+    for (int i = 0; i < N; ++i)
+      if (i > j) {
+        double l = a[i * N + j] * inv;
+        a[i * N + j] = l;
+        CHMC_UNROLL
+        for (int k = 0; k < N; ++k)
+          if (k > j) a[i * N + k] -= l * a[j * N + k];
+      }
+  }
+}
+template <int N, int NR>
+CHMC_HD inline void lu_solve(const double* lu, const int* piv, double* b) {  // b [N][NR] in place
+  CHMC_UNROLL
+  for (int i = 0; i < N; ++i) {
+    int p = piv[i];
+    CHMC_UNROLL
+    for (int t = 0; t < N; ++t)
+      if (t > i && t == p) {
+        CHMC_UNROLL
+        for (int c = 0; c < NR; ++c) {
+          double s = b[i * NR + c];
+          b[i * NR + c] = b[t * NR + c];
+          b[t * NR + c] = s;
+        }
+      }
+  }
+  CHMC_UNROLL
+  for (int c = 0; c < NR; ++c) {
+    CHMC_UNROLL
+    for (int i = 0; i < N; ++i) {
+      double t = b[i * NR + c];
+      CHMC_UNROLL
+      for (int k = 0; k < N; ++k)
+        if (k < i) t -= lu[i * N + k] * b[k * NR + c];
+      b[i * NR + c] = t;
+    }
+    CHMC_UNROLL
+    for (int i = N - 1; i >= 0; --i) {
+      double t = b[i * NR + c];
+      CHMC_UNROLL
+      for (int k = 0; k < N; ++k)
+        if (k > i) t -= lu[i * N + k] * b[k * NR + c];
+      b[i * NR + c] = t / lu[i * N + i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-(chain, block) scans
+template <class M>
+struct ChainConsts {
+  double z[M::Z];
+  double k[M::NK];
+  CHMC_HD void init(const double* u, double dl) {
+    M::gz(u, z);
+    M::precompute(z, dl, k);
+  }
+};
+
+// One block of `constr` (:473-519): generate_y_bar (:399-411) minus y_bar (:447-470).
+// traj (may be null) receives nsteps+1 states; cp receives RM padded constraint values.
+template <class M, int RM>
+CHMC_HD inline void fwd_block(const Sys& sy, const BlockDesc& bd, const ChainConsts<M>& cc, const double* q,
+                              const double* xobs, double* traj, double* cp) {
+  constexpr int X = M::X, V = M::V;
+  double x[X], xn[X];
+  const double* vb = q + sy.U;
+  if (bd.first) {
+    M::gx0(cc.z, vb, x);
+  } else {
+    for (int a = 0; a < X; ++a) x[a] = xobs[(bd.obs0 - 1) * X + a];
+  }
+  const double* v = vb + sy.V0 + (size_t)bd.step0 * V;
+  const double* n = q + sy.U + sy.NV;
+  for (int i = 0; i < RM; ++i) cp[i] = 0.0;
+  int s = 0;
+  for (int j = 0; j < bd.nobs; ++j) {
+    for (int i = 0; i < sy.S; ++i, ++s) {
+      if (traj)
+        for (int a = 0; a < X; ++a) traj[(size_t)s * X + a] = x[a];
+      M::step(cc.k, x, v + (size_t)s * V, xn);
+      for (int a = 0; a < X; ++a) x[a] = xn[a];
+    }
+    if (j < bd.ny) {
+      double yv = M::obs(x);
+      if (sy.noisy) yv += sy.sigma * n[bd.obs0 + j];
+      cp[j] = yv - sy.y[bd.obs0 + j];
+    }
+  }
+  if (traj)
+    for (int a = 0; a < X; ++a) traj[(size_t)s * X + a] = x[a];
+  if (!bd.last)
+    for (int a = 0; a < X; ++a) cp[bd.ny + a] = x[a] - xobs[(bd.obs0 + bd.nobs - 1) * X + a];
+}
+
+// Reverse (adjoint) sweep over a block carrying all RM constraint rows (jacob_constr_blocks :521-624).
+// MODE 0: store dc/dv rows into Jv_out and accumulate the symmetric Gram block D = Jv Jv^T (:765-792).
+// MODE 1: do not store; accumulate D = Jv(q) Jv(q_prev)^T against the stored rows Jr (:742-744).
+// JuL receives the RM x U rows of dc/du.  D is RM x RM, identity-padded, noise term added.
+template <class M, int RM, int MODE>
+CHMC_HD inline void rev_block(const Sys& sy, const BlockDesc& bd, const ChainConsts<M>& cc, const double* u,
+                              const double* q, const double* traj, double* Jv_out, const double* Jr, double* JuL,
+                              double* D) {
+  constexpr int X = M::X, V = M::V, Z = M::Z;
+  const int S = sy.S, L = bd.nsteps, NV = sy.NV;
+  double Lam[RM * X], zbar[RM * Z];
+  for (int i = 0; i < RM * X; ++i) Lam[i] = 0.0;
+  for (int i = 0; i < RM * Z; ++i) zbar[i] = 0.0;
+  for (int i = 0; i < RM * RM; ++i) D[i] = 0.0;
+  const double* v = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
+  int next_obs = bd.nobs;  // observation whose time is the end of the current interval
+  int cnt = 0;             // steps until that observation time is crossed
+  for (int st = L - 1; st >= 0; --st) {
+    if (cnt == 0) {  // st + 1 == next_obs * S
+      const int j = next_obs - 1;
+      if (j < bd.ny) {
+        double g[X];
+        M::obs_grad(traj + (size_t)(st + 1) * X, g);
+        CHMC_UNROLL
+        for (int i = 0; i < RM; ++i)
+          if (i == j)
+            for (int a = 0; a < X; ++a) Lam[i * X + a] = g[a];
+      }
+      if (st + 1 == L && !bd.last) {
+        CHMC_UNROLL
+        for (int i = 0; i < RM; ++i)
+          for (int a = 0; a < X; ++a)
+            if (i == bd.ny + a) Lam[i * X + a] = 1.0;
+      }
+      --next_obs;
+      cnt = S;
+    }
+    --cnt;
+    double A[X * X], Bm[X * V], Zf[X * Z];
+    M::jac(cc.k, traj + (size_t)st * X, v + (size_t)st * V, A, Bm, Zf);
+    double jr[RM * V];
+    CHMC_UNROLL
+    for (int i = 0; i < RM; ++i) {
+      CHMC_UNROLL
+      for (int c = 0; c < V; ++c) {
+        double t = 0.0;
+        CHMC_UNROLL
+        for (int a = 0; a < X; ++a) t += Lam[i * X + a] * Bm[a * V + c];
+        jr[i * V + c] = t;
+      }
+    }
+    const size_t col = colb + (size_t)st * V;
+    if (MODE == 0) {
+      CHMC_UNROLL
+      for (int i = 0; i < RM; ++i) {
+        CHMC_UNROLL
+        for (int c = 0; c < V; ++c) Jv_out[(size_t)i * NV + col + c] = jr[i * V + c];
+      }
+      CHMC_UNROLL
+      for (int i = 0; i < RM; ++i) {
+        CHMC_UNROLL
+        for (int j = 0; j <= i; ++j) {
+          double t = D[i * RM + j];
+          CHMC_UNROLL
+          for (int c = 0; c < V; ++c) t += jr[i * V + c] * jr[j * V + c];
+          D[i * RM + j] = t;
+        }
+      }
+    } else {
+      double jp[RM * V];
+      CHMC_UNROLL
+      for (int i = 0; i < RM; ++i) {
+        CHMC_UNROLL
+        for (int c = 0; c < V; ++c) jp[i * V + c] = Jr[(size_t)i * NV + col + c];
+      }
+      CHMC_UNROLL
+      for (int i = 0; i < RM; ++i) {
+        CHMC_UNROLL
+        for (int j = 0; j < RM; ++j) {
+          double t = D[i * RM + j];
+          CHMC_UNROLL
+          for (int c = 0; c < V; ++c) t += jr[i * V + c] * jp[j * V + c];
+          D[i * RM + j] = t;
+        }
+      }
+    }
+    CHMC_UNROLL
+    for (int i = 0; i < RM; ++i) {
+      CHMC_UNROLL
+      for (int mz = 0; mz < Z; ++mz) {
+        double t = zbar[i * Z + mz];
+        CHMC_UNROLL
+        for (int a = 0; a < X; ++a) t += Lam[i * X + a] * Zf[a * Z + mz];
+        zbar[i * Z + mz] = t;
+      }
+      double nl[X];
+      CHMC_UNROLL
+      for (int c = 0; c < X; ++c) {
+        double t = 0.0;
+        CHMC_UNROLL
+        for (int a = 0; a < X; ++a) t += Lam[i * X + a] * A[a * X + c];
+        nl[c] = t;
+      }
+      CHMC_UNROLL
+      for (int c = 0; c < X; ++c) Lam[i * X + c] = nl[c];
+    }
+  }
+  if (bd.first) {  // x_0 = generate_x_0(z, v_0): columns of v_0 and the z-dependence (:401, :566-567)
+    double dz[X * Z], dv0[X * M::V0];
+    M::gx0_jac(dz, dv0);
+    double j0[RM * M::V0];
+    for (int i = 0; i < RM; ++i) {
+      for (int c = 0; c < M::V0; ++c) {
+        double t = 0.0;
+        for (int a = 0; a < X; ++a) t += Lam[i * X + a] * dv0[a * M::V0 + c];
+        j0[i * M::V0 + c] = t;
+      }
+      for (int mz = 0; mz < Z; ++mz) {
+        double t = 0.0;
+        for (int a = 0; a < X; ++a) t += Lam[i * X + a] * dz[a * Z + mz];
+        zbar[i * Z + mz] += t;
+      }
+    }
+    if (MODE == 0) {
+      for (int i = 0; i < RM; ++i)
+        for (int c = 0; c < M::V0; ++c) Jv_out[(size_t)i * NV + c] = j0[i * M::V0 + c];
+      for (int i = 0; i < RM; ++i)
+        for (int j = 0; j <= i; ++j)
+          for (int c = 0; c < M::V0; ++c) D[i * RM + j] += j0[i * M::V0 + c] * j0[j * M::V0 + c];
+    } else {
+      for (int i = 0; i < RM; ++i)
+        for (int j = 0; j < RM; ++j)
+          for (int c = 0; c < M::V0; ++c) D[i * RM + j] += j0[i * M::V0 + c] * Jr[(size_t)j * NV + c];
+    }
+  }
+  if (MODE == 0) {
+    for (int i = 0; i < RM; ++i)
+      for (int j = 0; j < i; ++j) D[j * RM + i] = D[i * RM + j];
+  }
+  const double s2 = sy.sigma * sy.sigma;
+  for (int i = 0; i < RM; ++i) {
+    if (sy.noisy && i < bd.ny) D[i * RM + i] += s2;  // dc/dn dc/dn^T (:772-791)
+    if (i >= bd.nrows) D[i * RM + i] = 1.0;          // identity padding
+  }
+  double G[Z * Z];
+  M::gz_jac(u, G);
+  for (int i = 0; i < RM; ++i)
+    for (int c = 0; c < Z; ++c) {
+      double t = 0.0;
+      for (int mz = 0; mz < Z; ++mz) t += zbar[i * Z + mz] * G[mz * Z + c];
+      JuL[i * Z + c] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// kernels (functors)
+#define CHMC_CB_DECODE                   \
+  const int c = tid / sy.K;              \
+  const int b = tid - c * sy.K;          \
+  const BlockDesc bd = sy.blk[b];
+
+// constr only (quasi-Newton iterations, per-op API).  qsel: 0 slot `which`, 1 work.qb
+template <class M, int RM>
+struct KFwd {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which, qsel, use_nw, store_traj;
+  CHMC_HD void operator()(int tid) const {
+    CHMC_CB_DECODE
+    if (use_nw ? !w.nw[c] : !w.ok[c]) return;
+    const int s = sl.cur[c] ^ which;
+    const double* q = (qsel ? w.qb : sl.q[s]) + (size_t)c * sy.Q;
+    ChainConsts<M> cc;
+    cc.init(q, sy.dl);
+    double* traj = store_traj ? sl.traj[s] + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * M::X : nullptr;
+    double cp[RM];
+    fwd_block<M, RM>(sy, bd, cc, q, sy.xobs + (size_t)c * sy.T * M::X, traj, cp);
+    double* out = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
+    for (int i = 0; i < RM; ++i) out[i] = cp[i];
+  }
+};
+
+// generate_x_obs_seq (:384-397): one work item per chain
+template <class M>
+struct KXobs {
+  Sys sy;
+  Slots sl;
+  double* xobs_out;
+  CHMC_HD void operator()(int c) const {
+    constexpr int X = M::X, V = M::V;
+    const double* q = sl.q[sl.cur[c]] + (size_t)c * sy.Q;
+    ChainConsts<M> cc;
+    cc.init(q, sy.dl);
+    double x[X], xn[X];
+    M::gx0(cc.z, q + sy.U, x);
+    const double* v = q + sy.U + sy.V0;
+    double* out = xobs_out + (size_t)c * sy.T * X;
+    for (int t = 0; t < sy.T; ++t) {
+      for (int i = 0; i < sy.S; ++i) {
+        M::step(cc.k, x, v, xn);
+        for (int a = 0; a < X; ++a) x[a] = xn[a];
+        v += V;
+      }
+      for (int a = 0; a < X; ++a) out[t * X + a] = x[a];
+    }
+  }
+};
+
+// State evaluation, block part: trajectory, Jacobian rows, Gram block, its Cholesky factor,
+// D^-1 dc/du and this block's contribution to C (jacob_constr_blocks + chol_gram_blocks :626-687)
+template <class M, int RM>
+struct KStateBlk {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which;
+  CHMC_HD void operator()(int tid) const {
+    CHMC_CB_DECODE
+    if (!w.ok[c]) return;
+    constexpr int U = M::Z;
+    const int s = sl.cur[c] ^ which;
+    const double* q = sl.q[s] + (size_t)c * sy.Q;
+    ChainConsts<M> cc;
+    cc.init(q, sy.dl);
+    double* traj = sl.traj[s] + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * M::X;
+    double cp[RM];
+    fwd_block<M, RM>(sy, bd, cc, q, sy.xobs + (size_t)c * sy.T * M::X, traj, cp);
+    double* cout_ = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
+    for (int i = 0; i < RM; ++i) cout_[i] = cp[i];
+    double D[RM * RM], Ju[RM * U];
+    rev_block<M, RM, 0>(sy, bd, cc, q, q, traj, sl.Jv[s] + (size_t)c * RM * sy.NV, nullptr, Ju, D);
+    const size_t cb = (size_t)c * sy.Kmax + b;
+    double ld = chol_lower<RM>(D);
+    double* fd = sl.facD[s] + cb * RM * RM;
+    for (int i = 0; i < RM * RM; ++i) fd[i] = D[i];
+    sl.ldb[s][cb] = ld;
+    double* ju = sl.JuP[s] + cb * RM * U;
+    for (int i = 0; i < RM * U; ++i) ju[i] = Ju[i];
+    double E[RM * U];
+    for (int i = 0; i < RM * U; ++i) E[i] = Ju[i];
+    cho_solve<RM, U>(D, E);
+    double* eo = sl.E[s] + cb * RM * U;
+    for (int i = 0; i < RM * U; ++i) eo[i] = E[i];
+    double* Cb = w.Cb + cb * U * U;
+    for (int a = 0; a < U; ++a)
+      for (int d = 0; d < U; ++d) {
+        double t = 0.0;
+        for (int i = 0; i < RM; ++i) t += Ju[i * U + a] * E[i * U + d];
+        Cb[a * U + d] = t;
+      }
+  }
+};
+
+// State evaluation, chain part: C = M_0 + sum_b Ju_b^T D_b^-1 Ju_b, its Cholesky factor and inverse,
+// 1/2 log det Gram (:676-686, :800-810)
+template <class M>
+struct KStateChain {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which;
+  CHMC_HD void operator()(int c) const {
+    if (!w.ok[c]) return;
+    constexpr int U = M::Z;
+    const int s = sl.cur[c] ^ which;
+    double Cm[U * U];
+    for (int i = 0; i < U * U; ++i) Cm[i] = 0.0;
+    for (int i = 0; i < U; ++i) Cm[i * U + i] = 1.0;
+    double ld = 0.0;
+    for (int b = 0; b < sy.K; ++b) {
+      const double* Cb = w.Cb + ((size_t)c * sy.Kmax + b) * U * U;
+      for (int i = 0; i < U * U; ++i) Cm[i] += Cb[i];
+      ld += sl.ldb[s][(size_t)c * sy.Kmax + b];
+    }
+    ld += chol_lower<U>(Cm);
+    double Ci[U * U];
+    for (int i = 0; i < U * U; ++i) Ci[i] = 0.0;
+    for (int i = 0; i < U; ++i) Ci[i * U + i] = 1.0;
+    cho_solve<U, U>(Cm, Ci);
+    for (int i = 0; i < U * U; ++i) {
+      sl.facC[s][(size_t)c * U * U + i] = Cm[i];
+      sl.Cinv[s][(size_t)c * U * U + i] = Ci[i];
+    }
+    sl.logdet[s][c] = ld;
+  }
+};
+
+// Gradient of 1/2 log det Gram, block part (value_and_grad of log_det_sqrt_gram :812-820, :1143-1146):
+// grad = sum_i grad_q [ grad c_i . w_i ],  W = G^-1 J on J's block pattern, i.e. per block one tangent
+// sweep per row along w_i and one second-order adjoint sweep with the sources summed over rows.
+template <class M, int RM>
+struct KGldBlk {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which;
+  CHMC_HD void operator()(int tid) const {
+    CHMC_CB_DECODE
+    if (!w.ok[c]) return;
+    constexpr int X = M::X, V = M::V, Z = M::Z, U = M::Z, V0 = M::V0, NXI = M::NXI;
+    const int s = sl.cur[c] ^ which;
+    const int S = sy.S, L = bd.nsteps, NV = sy.NV;
+    const size_t cb = (size_t)c * sy.Kmax + b;
+    const double* q = sl.q[s] + (size_t)c * sy.Q;
+    const double* traj = sl.traj[s] + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+    const double* Jv = sl.Jv[s] + (size_t)c * RM * NV;
+    const double* v = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+    const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
+    double* gv = sl.grad[s] + (size_t)c * sy.Q + sy.U;
+    double* Xd = w.Xd + ((size_t)c * sy.T * S + bd.step0) * RM * X;
+    ChainConsts<M> cc;
+    cc.init(q, sy.dl);
+    double Gz[Z * Z], dx0dz[X * Z], dx0dv0[X * V0];
+    M::gz_jac(q, Gz);
+    M::gx0_jac(dx0dz, dx0dv0);
+    // Wu = D^-1 Ju C^-1 (rows of G^-1 dc/du);  Mb = (G^-1)_bb = D^-1 - E C^-1 E^T
+    double Wu[RM * U], Mb[RM * RM], zd[RM * Z];
+    {
+      const double* E = sl.E[s] + cb * RM * U;
+      const double* Ci = sl.Cinv[s] + (size_t)c * U * U;
+      double Dl[RM * RM];
+      const double* fd = sl.facD[s] + cb * RM * RM;
+      for (int i = 0; i < RM * RM; ++i) Dl[i] = fd[i];
+      for (int i = 0; i < RM; ++i)
+        for (int d = 0; d < U; ++d) {
+          double t = 0.0;
+          for (int a = 0; a < U; ++a) t += E[i * U + a] * Ci[a * U + d];
+          Wu[i * U + d] = t;
+        }
+      for (int i = 0; i < RM * RM; ++i) Mb[i] = 0.0;
+      for (int i = 0; i < RM; ++i) Mb[i * RM + i] = 1.0;
+      cho_solve<RM, RM>(Dl, Mb);
+      for (int i = 0; i < RM; ++i)
+        for (int j = 0; j < RM; ++j) {
+          double t = 0.0;
+          for (int a = 0; a < U; ++a) t += Wu[i * U + a] * E[j * U + a];
+          Mb[i * RM + j] -= t;
+        }
+      for (int i = 0; i < RM; ++i) {
+        if (i >= bd.nrows)  // padded rows carry no constraint
+          for (int j = 0; j < RM; ++j) Mb[i * RM + j] = 0.0, Mb[j * RM + i] = 0.0;
+        for (int mz = 0; mz < Z; ++mz) {
+          double t = 0.0;
+          for (int d = 0; d < U; ++d) t += Gz[mz * Z + d] * Wu[i * U + d];
+          zd[i * Z + mz] = t;
+        }
+      }
+    }
+    // forward tangent sweeps
+    double xd[RM * X], xdt[RM * X];
+    for (int i = 0; i < RM * X; ++i) xd[i] = 0.0, xdt[i] = 0.0;
+    if (bd.first)
+      for (int i = 0; i < RM; ++i)
+        for (int a = 0; a < X; ++a) {
+          double t = 0.0;
+          for (int mz = 0; mz < Z; ++mz) t += dx0dz[a * Z + mz] * zd[i * Z + mz];
+          for (int d = 0; d < V0; ++d) {
+            double wv = 0.0;
+            for (int j = 0; j < RM; ++j) wv += Mb[i * RM + j] * Jv[(size_t)j * NV + d];
+            t += dx0dv0[a * V0 + d] * wv;
+          }
+          xd[i * X + a] = t;
+        }
+    {
+      int cnt = S, jobs = 0;
+      for (int st = 0; st < L; ++st) {
+        for (int i = 0; i < RM * X; ++i) Xd[(size_t)st * RM * X + i] = xd[i];
+        double A[X * X], Bm[X * V], Zf[X * Z], jp[RM * V];
+        M::jac(cc.k, traj + (size_t)st * X, v + (size_t)st * V, A, Bm, Zf);
+        const size_t col = colb + (size_t)st * V;
+        CHMC_UNROLL
+        for (int j = 0; j < RM; ++j) {
+          CHMC_UNROLL
+          for (int d = 0; d < V; ++d) jp[j * V + d] = Jv[(size_t)j * NV + col + d];
+        }
+        CHMC_UNROLL
+        for (int i = 0; i < RM; ++i) {
+          double wv[V], nx[X];
+          CHMC_UNROLL
+          for (int d = 0; d < V; ++d) {
+            double t = 0.0;
+            CHMC_UNROLL
+            for (int j = 0; j < RM; ++j) t += Mb[i * RM + j] * jp[j * V + d];
+            wv[d] = t;
+          }
+          CHMC_UNROLL
+          for (int a = 0; a < X; ++a) {
+            double t = 0.0;
+            CHMC_UNROLL
+            for (int d = 0; d < X; ++d) t += A[a * X + d] * xd[i * X + d];
+            CHMC_UNROLL
+            for (int d = 0; d < V; ++d) t += Bm[a * V + d] * wv[d];
+            CHMC_UNROLL
+            for (int mz = 0; mz < Z; ++mz) t += Zf[a * Z + mz] * zd[i * Z + mz];
+            nx[a] = t;
+          }
+          CHMC_UNROLL
+          for (int a = 0; a < X; ++a) xd[i * X + a] = nx[a];
+        }
+        if (--cnt == 0) {  // st + 1 is the time of local observation `jobs`
+          if (jobs < bd.ny) {
+            CHMC_UNROLL
+            for (int i = 0; i < RM; ++i)
+              if (i == jobs)
+                for (int a = 0; a < X; ++a) xdt[i * X + a] = xd[i * X + a];
+          }
+          ++jobs;
+          cnt = S;
+        }
+      }
+    }
+    // backward second-order sweep
+    double Lam[RM * X], zbar[RM * Z], xbar[X], zbt[Z];
+    for (int i = 0; i < RM * X; ++i) Lam[i] = 0.0;
+    for (int i = 0; i < RM * Z; ++i) zbar[i] = 0.0;
+    for (int a = 0; a < X; ++a) xbar[a] = 0.0;
+    for (int a = 0; a < Z; ++a) zbt[a] = 0.0;
+    int next_obs = bd.nobs, cnt = 0;
+    for (int st = L - 1; st >= 0; --st) {
+      if (cnt == 0) {
+        const int j = next_obs - 1;
+        if (j < bd.ny) {
+          double g[X], hv[X], xt[X];
+          CHMC_UNROLL
+          for (int i = 0; i < RM; ++i)
+            if (i == j)
+              for (int a = 0; a < X; ++a) xt[a] = xdt[i * X + a];
+          M::obs_grad(traj + (size_t)(st + 1) * X, g);
+          M::obs_hess_vec(traj + (size_t)(st + 1) * X, xt, hv);
+          CHMC_UNROLL
+          for (int i = 0; i < RM; ++i)
+            if (i == j)
+              for (int a = 0; a < X; ++a) Lam[i * X + a] = g[a];
+          for (int a = 0; a < X; ++a) xbar[a] += hv[a];
+        }
+        if (st + 1 == L && !bd.last) {
+          CHMC_UNROLL
+          for (int i = 0; i < RM; ++i)
+            for (int a = 0; a < X; ++a)
+              if (i == bd.ny + a) Lam[i * X + a] = 1.0;
+        }
+        --next_obs;
+        cnt = S;
+      }
+      --cnt;
+      double A[X * X], Bm[X * V], Zf[X * Z], jp[RM * V], Sm[X * NXI], H[NXI];
+      M::jac(cc.k, traj + (size_t)st * X, v + (size_t)st * V, A, Bm, Zf);
+      const size_t col = colb + (size_t)st * V;
+      CHMC_UNROLL
+      for (int j = 0; j < RM; ++j) {
+        CHMC_UNROLL
+        for (int d = 0; d < V; ++d) jp[j * V + d] = Jv[(size_t)j * NV + col + d];
+      }
+      for (int i = 0; i < X * NXI; ++i) Sm[i] = 0.0;
+      const double* xds = Xd + (size_t)st * RM * X;
+      CHMC_UNROLL
+      for (int i = 0; i < RM; ++i) {
+        double dir[NXI];
+        CHMC_UNROLL
+        for (int a = 0; a < X; ++a) dir[a] = xds[i * X + a];
+        CHMC_UNROLL
+        for (int d = 0; d < V; ++d) {
+          double t = 0.0;
+          CHMC_UNROLL
+          for (int j = 0; j < RM; ++j) t += Mb[i * RM + j] * jp[j * V + d];
+          dir[X + d] = t;
+        }
+        CHMC_UNROLL
+        for (int mz = 0; mz < Z; ++mz) dir[X + V + mz] = zd[i * Z + mz];
+        CHMC_UNROLL
+        for (int a = 0; a < X; ++a) {
+          CHMC_UNROLL
+          for (int m2 = 0; m2 < NXI; ++m2) Sm[a * NXI + m2] += Lam[i * X + a] * dir[m2];
+        }
+      }
+      M::hess(cc.k, traj + (size_t)st * X, v + (size_t)st * V, Sm, H);
+      for (int d = 0; d < V; ++d) {
+        double t = H[X + d];
+        for (int a = 0; a < X; ++a) t += Bm[a * V + d] * xbar[a];
+        gv[col + d] = t;
+      }
+      for (int mz = 0; mz < Z; ++mz) {
+        double t = H[X + V + mz];
+        for (int a = 0; a < X; ++a) t += Zf[a * Z + mz] * xbar[a];
+        zbt[mz] += t;
+      }
+      double nxb[X];
+      for (int d = 0; d < X; ++d) {
+        double t = H[d];
+        for (int a = 0; a < X; ++a) t += A[a * X + d] * xbar[a];
+        nxb[d] = t;
+      }
+      for (int d = 0; d < X; ++d) xbar[d] = nxb[d];
+      CHMC_UNROLL
+      for (int i = 0; i < RM; ++i) {
+        CHMC_UNROLL
+        for (int mz = 0; mz < Z; ++mz) {
+          double t = zbar[i * Z + mz];
+          CHMC_UNROLL
+          for (int a = 0; a < X; ++a) t += Lam[i * X + a] * Zf[a * Z + mz];
+          zbar[i * Z + mz] = t;
+        }
+        double nl[X];
+        CHMC_UNROLL
+        for (int d = 0; d < X; ++d) {
+          double t = 0.0;
+          CHMC_UNROLL
+          for (int a = 0; a < X; ++a) t += Lam[i * X + a] * A[a * X + d];
+          nl[d] = t;
+        }
+        CHMC_UNROLL
+        for (int d = 0; d < X; ++d) Lam[i * X + d] = nl[d];
+      }
+    }
+    if (bd.first) {
+      for (int d = 0; d < V0; ++d) {
+        double t = 0.0;
+        for (int a = 0; a < X; ++a) t += dx0dv0[a * V0 + d] * xbar[a];
+        gv[d] = t;
+      }
+      for (int mz = 0; mz < Z; ++mz) {
+        double t = 0.0;
+        for (int a = 0; a < X; ++a) t += dx0dz[a * Z + mz] * xbar[a];
+        zbt[mz] += t;
+      }
+      for (int i = 0; i < RM; ++i)
+        for (int mz = 0; mz < Z; ++mz) {
+          double t = 0.0;
+          for (int a = 0; a < X; ++a) t += Lam[i * X + a] * dx0dz[a * Z + mz];
+          zbar[i * Z + mz] += t;
+        }
+    }
+    double gu[U];
+    for (int d = 0; d < U; ++d) {
+      double t = 0.0;
+      for (int mz = 0; mz < Z; ++mz) t += Gz[mz * Z + d] * zbt[mz];
+      gu[d] = t;
+    }
+    for (int i = 0; i < RM; ++i) {
+      double o[Z];
+      M::gz_hess(q, Wu + i * U, zbar + i * Z, o);
+      for (int d = 0; d < U; ++d) gu[d] += o[d];
+    }
+    for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
+  }
+};
+
+template <class M>
+struct KGldChain {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which;
+  CHMC_HD void operator()(int c) const {
+    if (!w.ok[c]) return;
+    constexpr int U = M::Z;
+    const int s = sl.cur[c] ^ which;
+    double* g = sl.grad[s] + (size_t)c * sy.Q;
+    for (int d = 0; d < U; ++d) {
+      double t = 0.0;
+      for (int b = 0; b < sy.K; ++b) t += w.gup[((size_t)c * sy.Kmax + b) * U + d];
+      g[d] = t;
+    }
+    if (sy.noisy)  // fixed observation noise: the Gram matrix does not depend on n
+      for (int t = 0; t < sy.T; ++t) g[sy.U + sy.NV + t] = 0.0;
+  }
+};
+
+// Newton iteration, block part (body of newton_projection :1088-1104): constraint, Jacobian of the
+// iterate contracted on the fly with the stored Jacobian of the previous point, LU of the block,
+// D^-1 c, D^-1 dc/du and this block's share of C and of dc/du_prev^T D^-1 c.
+template <class M, int RM>
+struct KNewtonBlk {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int prev, qsel;  // prev: slot (0/1) holding J(q_prev); qsel: 0 iterate = other slot's q, 1 iterate = work.qb
+  CHMC_HD void operator()(int tid) const {
+    CHMC_CB_DECODE
+    if (!w.nw[c]) return;
+    constexpr int U = M::Z;
+    const int sp = sl.cur[c] ^ prev;
+    const double* q = (qsel ? w.qb : sl.q[sp ^ 1]) + (size_t)c * sy.Q;
+    ChainConsts<M> cc;
+    cc.init(q, sy.dl);
+    double* traj = w.trajw + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * M::X;
+    double cp[RM];
+    fwd_block<M, RM>(sy, bd, cc, q, sy.xobs + (size_t)c * sy.T * M::X, traj, cp);
+    const size_t cb = (size_t)c * sy.Kmax + b;
+    double* cout_ = w.cpad + cb * RM;
+    for (int i = 0; i < RM; ++i) cout_[i] = cp[i];
+    double D[RM * RM], JuL[RM * U];
+    rev_block<M, RM, 1>(sy, bd, cc, q, q, traj, nullptr, sl.Jv[sp] + (size_t)c * RM * sy.NV, JuL, D);
+    int piv[RM];
+    lu_factor<RM>(D, piv);
+    lu_solve<RM, 1>(D, piv, cp);
+    lu_solve<RM, U>(D, piv, JuL);
+    double* to = w.tpad + cb * RM;
+    for (int i = 0; i < RM; ++i) to[i] = cp[i];
+    double* eo = w.Ew + cb * RM * U;
+    for (int i = 0; i < RM * U; ++i) eo[i] = JuL[i];
+    const double* jur = sl.JuP[sp] + cb * RM * U;
+    double* Cb = w.Cb + cb * U * U;
+    double* sb = w.sb + cb * U;
+    for (int a = 0; a < U; ++a) {
+      double t2 = 0.0;
+      for (int i = 0; i < RM; ++i) t2 += jur[i * U + a] * cp[i];
+      sb[a] = t2;
+      for (int d = 0; d < U; ++d) {
+        double t = 0.0;
+        for (int i = 0; i < RM; ++i) t += jur[i * U + a] * JuL[i * U + d];
+        Cb[a * U + d] = t;
+      }
+    }
+  }
+};
+
+// Symmetric (Cholesky) block solve of an already stored padded vector: t = D^-1 v, s = Ju^T t
+// (first half of lmult_by_inv_gram :920-930).  Input vector: work.cpad.
+template <class M, int RM>
+struct KSymBlk {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which, use_nw;
+  CHMC_HD void operator()(int tid) const {
+    CHMC_CB_DECODE
+    if (use_nw ? !w.nw[c] : !w.ok[c]) return;
+    constexpr int U = M::Z;
+    const int s = sl.cur[c] ^ which;
+    const size_t cb = (size_t)c * sy.Kmax + b;
+    double Dl[RM * RM], t[RM];
+    const double* fd = sl.facD[s] + cb * RM * RM;
+    for (int i = 0; i < RM * RM; ++i) Dl[i] = fd[i];
+    for (int i = 0; i < RM; ++i) t[i] = w.cpad[cb * RM + i];
+    cho_solve<RM, 1>(Dl, t);
+    for (int i = 0; i < RM; ++i) w.tpad[cb * RM + i] = t[i];
+    const double* ju = sl.JuP[s] + cb * RM * U;
+    for (int a = 0; a < U; ++a) {
+      double acc = 0.0;
+      for (int i = 0; i < RM; ++i) acc += ju[i * U + a] * t[i];
+      w.sb[cb * U + a] = acc;
+    }
+  }
+};
+
+// Chain part of a Woodbury solve + the u-columns of the update.
+//  SYM 0 (Newton :944-981):  C = I + sum Cb (LU), y = C^-1 sum s_b, lambda_b = t_b - Ew_b y
+//  SYM 1 (Gram   :915-942):  C from the slot's Cholesky factor,     lambda_b = t_b - E_b y
+// (lambda_b = D_b^-1 (v_b - Ju_b y) computed as D_b^-1 v_b - (D_b^-1 Ju_b) y.)
+//  TGT 0: Newton / quasi-Newton update of the iterate: q_u -= d, mu_u += d, err = |c|_inf, ndq = |d_u|_inf
+//  TGT 1: momentum projection: p_u -= d  (target p selected by psel: 0 slot `which` p, 1 work.pb)
+//  TGT 2: no update (per-op API: multipliers only)
+template <class M, int RM, int SYM, int TGT>
+struct KSolveChain {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which, qsel, psel;  // which: slot holding the (previous-point) factors and dc/du
+  CHMC_HD void operator()(int c) const {
+    if (TGT == 0 ? !w.nw[c] : !w.ok[c]) return;
+    constexpr int U = M::Z;
+    const int s = sl.cur[c] ^ which;
+    double sacc[U];
+    for (int a = 0; a < U; ++a) sacc[a] = 0.0;
+    for (int b = 0; b < sy.K; ++b)
+      for (int a = 0; a < U; ++a) sacc[a] += w.sb[((size_t)c * sy.Kmax + b) * U + a];
+    if (SYM) {
+      double Lc[U * U];
+      for (int i = 0; i < U * U; ++i) Lc[i] = sl.facC[s][(size_t)c * U * U + i];
+      cho_solve<U, 1>(Lc, sacc);
+    } else {
+      double Cm[U * U];
+      int piv[U];
+      for (int i = 0; i < U * U; ++i) Cm[i] = 0.0;
+      for (int i = 0; i < U; ++i) Cm[i * U + i] = 1.0;
+      for (int b = 0; b < sy.K; ++b)
+        for (int i = 0; i < U * U; ++i) Cm[i] += w.Cb[((size_t)c * sy.Kmax + b) * U * U + i];
+      lu_factor<U>(Cm, piv);
+      lu_solve<U, 1>(Cm, piv, sacc);
+    }
+    double du[U];
+    for (int a = 0; a < U; ++a) du[a] = 0.0;
+    unsigned long long eb = 0ULL;
+    for (int b = 0; b < sy.K; ++b) {
+      const size_t cb = (size_t)c * sy.Kmax + b;
+      const double* E = (SYM ? sl.E[s] : w.Ew) + cb * RM * U;
+      const double* ju = sl.JuP[s] + cb * RM * U;
+      for (int i = 0; i < RM; ++i) {
+        double l = w.tpad[cb * RM + i];
+        for (int a = 0; a < U; ++a) l -= E[i * U + a] * sacc[a];
+        w.lampad[cb * RM + i] = l;
+        for (int a = 0; a < U; ++a) du[a] += ju[i * U + a] * l;
+        if (TGT == 0) {
+          unsigned long long vb = absbits(w.cpad[cb * RM + i]);
+          if (vb > eb) eb = vb;
+        }
+      }
+    }
+    if (TGT == 0) {
+      double* q = (qsel ? w.qb : sl.q[s ^ 1]) + (size_t)c * sy.Q;
+      double* mu = w.mu + (size_t)c * sy.Q;
+      unsigned long long nb = 0ULL;
+      for (int a = 0; a < U; ++a) {
+        q[a] -= du[a];
+        mu[a] += du[a];
+        unsigned long long vb = absbits(du[a]);
+        if (vb > nb) nb = vb;
+      }
+      w.err[c] = bitsd(eb);
+      w.ndq[c] = nb;
+    } else if (TGT == 1) {
+      double* p = (psel == 0 ? sl.p[s] : psel == 1 ? w.pb : sl.p[s ^ 1]) + (size_t)c * sy.Q;
+      for (int a = 0; a < U; ++a) p[a] -= du[a];
+    }
+  }
+};
+
+// Column-parallel part of J^T lambda (rmult_by_jacob_constr :879-913) fused with its consumer.
+//  TGT 0: q -= d, mu += d, ndq = max |d|     TGT 1: p -= d     TGT 2: out = d (work.pb, all columns incl. u)
+template <int RM, int TGT>
+struct KUpdate {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which, qsel, psel;
+  CHMC_HD void operator()(int tid) const {
+    const int c = tid / sy.NCOL;
+    const int col = tid - c * sy.NCOL;
+    if (TGT == 0 ? !w.nw[c] : !w.ok[c]) return;
+    const int s = sl.cur[c] ^ which;
+    double d;
+    if (col < sy.NV) {
+      int g = col < sy.V0 ? 0 : (col - sy.V0) / sy.V / sy.S;
+      const int b = sy.obs2blk[g];
+      const double* lam = w.lampad + ((size_t)c * sy.Kmax + b) * RM;
+      const double* Jv = sl.Jv[s] + (size_t)c * RM * sy.NV + col;
+      d = 0.0;
+      CHMC_UNROLL
+      for (int i = 0; i < RM; ++i) d += Jv[(size_t)i * sy.NV] * lam[i];
+    } else {
+      const int t = col - sy.NV;
+      const int b = sy.obs2blk[t];
+      const int j = t - sy.blk[b].obs0;
+      d = j < sy.blk[b].ny ? sy.sigma * w.lampad[((size_t)c * sy.Kmax + b) * RM + j] : 0.0;
+    }
+    const size_t qi = (size_t)c * sy.Q + sy.U + col;
+    if (TGT == 0) {
+      double* q = qsel ? w.qb : sl.q[s ^ 1];
+      q[qi] -= d;
+      w.mu[qi] += d;
+      atomic_max_u64(&w.ndq[c], absbits(d));
+    } else if (TGT == 1) {
+      double* p = psel == 0 ? sl.p[s] : psel == 1 ? w.pb : sl.p[s ^ 1];
+      p[qi] -= d;
+    } else {
+      w.pb[qi] = d;
+    }
+  }
+};
+
+// lax.while_loop condition (:1119-1127) evaluated per chain after each iteration, and the status mapping of
+// the host wrappers (:1462-1476): 0 converged, 1 did not converge, 2 diverged / NaN.
+struct KCheck {
+  Work w;
+  double ctol, ptol, dtol;
+  int max_iters, B;
+  CHMC_HD void operator()(int c) const {
+    if (!w.nw[c]) return;
+    const int i = ++w.iters[c];
+    const double err = w.err[c], ndq = bitsd(w.ndq[c]);
+    const bool diverged = (err > dtol) || (err != err);
+    const bool converged = (err < ctol) && (ndq < ptol);
+    if (i >= max_iters || diverged || converged) {
+      w.nw[c] = 0;
+      int st = converged ? 0 : (diverged ? 2 : 1);
+      w.nstat[c] = st;
+      if (st) w.ok[c] = 0, w.status[c] = st;
+    } else {
+      atomic_add_i32(w.n_active, 1);
+    }
+  }
+};
+
+struct KNewtonBegin {
+  Work w;
+  CHMC_HD void operator()(int c) const {
+    w.nw[c] = w.ok[c];
+    w.iters[c] = 0;
+    w.err[c] = -1.0;
+    w.ndq[c] = 0x7ff0000000000000ULL;  // +inf
+    w.nstat[c] = 0;
+    if (w.ok[c]) atomic_add_i32(w.n_active, 1);
+  }
+};
+
+// J w, one work item per (chain, block, row) (lmult_by_jacob_constr :822-877); input vector selected by
+// vsel (0: slot p, 1: work.pb, 2: work.vin); result in work.cpad
+template <int RM>
+struct KJw {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which, vsel;
+  CHMC_HD void operator()(int tid) const {
+    const int i = tid % RM;
+    const int cbk = tid / RM;
+    const int c = cbk / sy.K;
+    const int b = cbk - c * sy.K;
+    if (!w.ok[c]) return;
+    const BlockDesc bd = sy.blk[b];
+    const int s = sl.cur[c] ^ which;
+    const double* vct = (vsel == 0 ? sl.p[s] : vsel == 1 ? w.pb : vsel == 2 ? w.vin : sl.p[s ^ 1]) + (size_t)c * sy.Q;
+    const size_t cb = (size_t)c * sy.Kmax + b;
+    double acc = 0.0;
+    if (i < bd.nrows) {
+      const double* ju = sl.JuP[s] + (cb * RM + i) * sy.U;
+      for (int a = 0; a < sy.U; ++a) acc += ju[a] * vct[a];
+      const double* Jv = sl.Jv[s] + ((size_t)c * RM + i) * sy.NV + bd.col0;
+      const double* wv = vct + sy.U + bd.col0;
+      double a2 = 0.0;
+      for (int k = 0; k < bd.ncols; ++k) a2 += Jv[k] * wv[k];
+      acc += a2;
+      if (sy.noisy && i < bd.ny) acc += sy.sigma * vct[sy.U + sy.NV + bd.obs0 + i];
+    }
+    w.cpad[cb * RM + i] = acc;
+  }
+};
+
+// element-wise pieces of the integrator (one work item per (chain, component))
+// _step_a first half: p_out = p_in - h * dh1_dpos (:1192-1196), h = hfrac * dt[c]; q, grad and p_in are those
+// of slot `which`; out_other != 0 writes the result into the other slot's p (leaving p_in untouched)
+struct KKick {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which, out_other;
+  double hfrac;
+  CHMC_HD void operator()(int tid) const {
+    const int c = tid / sy.Q;
+    if (!w.ok[c]) return;
+    const int s = sl.cur[c] ^ which;
+    const double h = hfrac * w.dt[c];
+    const double g = sl.grad[s][tid] + (sy.gaussian ? 0.0 : sl.q[s][tid]);
+    const double pin = sl.p[s][tid];
+    (out_other ? sl.p[s ^ 1] : sl.p[s])[tid] = pin - h * g;
+  }
+};
+// h2_flow (:1222-1231) from slot `from` into (q_out, p_out): dst 0 = other slot, dst 1 = work (qb, pb)
+struct KFlow {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int from, dst, from_p_other;
+  double sign;
+  CHMC_HD void operator()(int tid) const {
+    const int c = tid / sy.Q;
+    if (!w.ok[c]) return;
+    const int s = sl.cur[c] ^ from;
+    const double dt = sign * w.dt[c];
+    const double q0 = sl.q[s][tid];
+    const double p0 = from_p_other ? sl.p[s ^ 1][tid] : sl.p[s][tid];
+    double qn, pn;
+    if (sy.gaussian) {
+      const double sn = sin(dt), cs = cos(dt);
+      qn = q0 * cs + sn * p0;
+      pn = p0 * cs - sn * q0;
+    } else {
+      qn = q0 + dt * p0;
+      pn = p0;
+    }
+    if (dst == 0) {
+      sl.q[s ^ 1][tid] = qn;
+      sl.p[s ^ 1][tid] = pn;
+    } else {
+      w.qb[tid] = qn;
+      w.pb[tid] = pn;
+    }
+  }
+};
+// momentum correction after a successful projection: p -= dh2_flow_mom_dmom @ (mu / dt) (:1233-1238, :1465)
+struct KMomFix {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which;
+  CHMC_HD void operator()(int tid) const {
+    const int c = tid / sy.Q;
+    if (!w.ok[c]) return;
+    const int s = sl.cur[c] ^ which;
+    const double dt = w.dt[c];
+    const double sc = sy.gaussian ? cos(dt) / sin(dt) : 1.0 / dt;
+    sl.p[s][tid] -= sc * w.mu[tid];
+  }
+};
+// reverse check distance max |q_back - q_start| (mici maximum_norm)
+struct KRevDiff {
+  Sys sy;
+  Slots sl;
+  Work w;
+  CHMC_HD void operator()(int tid) const {
+    const int c = tid / sy.Q;
+    if (!w.ok[c]) return;
+    const int s = sl.cur[c];
+    atomic_max_u64(&w.rev[c], absbits(w.qb[tid] - sl.q[s][tid]));
+  }
+};
+struct KRevCheck {
+  Work w;
+  double tol;
+  CHMC_HD void operator()(int c) const {
+    if (!w.ok[c]) return;
+    const double r = bitsd(w.rev[c]);
+    if (!(r <= tol)) w.ok[c] = 0, w.status[c] = 3;
+  }
+};
+struct KCommit {  // accept: the proposal slot becomes the state slot
+  Slots sl;
+  Work w;
+  CHMC_HD void operator()(int c) const {
+    if (w.ok[c]) sl.cur[c] ^= 1;
+  }
+};
+struct KBegin {
+  Work w;
+  const int* active;
+  const double* dt;
+  CHMC_HD void operator()(int c) const {
+    w.ok[c] = active ? (active[c] != 0) : 1;
+    w.status[c] = w.ok[c] ? 0 : -1;
+    if (dt) w.dt[c] = dt[c];
+    w.rev[c] = 0ULL;
+  }
+};
+// partial sums of q.q and p.p for the Hamiltonian (:1186-1202): NPART partials per chain
+struct KNormPart {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int npart;
+  CHMC_HD void operator()(int tid) const {
+    const int c = tid / npart, j = tid - c * npart;
+    const int s = sl.cur[c];
+    const int chunk = (sy.Q + npart - 1) / npart;
+    const int lo = j * chunk, hi = lo + chunk < sy.Q ? lo + chunk : sy.Q;
+    double qq = 0.0, pp = 0.0;
+    const double* q = sl.q[s] + (size_t)c * sy.Q;
+    const double* p = sl.p[s] + (size_t)c * sy.Q;
+    for (int i = lo; i < hi; ++i) qq += q[i] * q[i], pp += p[i] * p[i];
+    w.part[((size_t)c * npart + j) * 2] = qq;
+    w.part[((size_t)c * npart + j) * 2 + 1] = pp;
+  }
+};
+struct KHamiltonian {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int npart;
+  double* out;  // [B][3]: h, 1/2 q.q, 1/2 p.p
+  CHMC_HD void operator()(int c) const {
+    double qq = 0.0, pp = 0.0;
+    for (int j = 0; j < npart; ++j) qq += w.part[((size_t)c * npart + j) * 2], pp += w.part[((size_t)c * npart + j) * 2 + 1];
+    const double ld = sl.logdet[sl.cur[c]][c];
+    out[c * 3 + 1] = 0.5 * qq;
+    out[c * 3 + 2] = 0.5 * pp;
+    out[c * 3] = 0.5 * qq + ld + 0.5 * pp;  // h1 + h2 is the same sum for both splittings
+  }
+};
+
+}  // namespace chmc

@@ -1,0 +1,19 @@
+// TEST-ONLY host "backend": runs every functor of chmc_core.h in a plain loop so that the kernel sequencing
+// logic of chmc_api.inc can be unit-tested in the GPU-less build container.  NOT part of the product: the
+// package loader (manifold_mcmc_for_diffusions_amd/_lib.py) only ever loads libchmc_hip.so.
+#pragma once
+#include <cstdlib>
+#include <cstring>
+static int dev_set(int) { return 0; }
+static int dev_init(int) { return 0; }
+static void* dev_alloc(size_t bytes) { return calloc(bytes ? bytes : 8, 1); }
+static void dev_free(void* p) { free(p); }
+static void dev_zero(void* p, size_t bytes) { memset(p, 0, bytes); }
+static void h2d(void* d, const void* h, size_t bytes) { memcpy(d, h, bytes); }
+static void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
+static void d2d(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
+static int dev_sync() { return 0; }
+template <class F>
+static void launch(F f, long n) {
+  for (long t = 0; t < n; ++t) f((int)t);
+}

@@ -1,0 +1,134 @@
+"""Shared test helpers: synthetic cases for the conditioned-diffusion system and oracle access.
+
+Test infrastructure only (may import oracle/)."""
+import numpy as np
+from oracle import c_oracle
+from manifold_mcmc_for_diffusions_amd import example_models as em
+
+FHN_U = np.array([-1.2, -2.0, 0.4, 0.8])  # log sigma, log eps, log gamma, beta  (sigma 0.3, eps 0.135, gamma 1.5)
+SIR_U = np.array([-1.0, -1.0, 1.0, 0.0])
+
+
+def random_q(model, T, S, noisy, B, rng, v_scale=0.3, u_scale=0.1):
+    m = em.MODELS[model]
+    Q = m.dim_z + m.dim_v_0 + T * S * m.dim_v + (T if noisy else 0)
+    q = np.zeros((B, Q))
+    u0 = FHN_U if model == "fhn" else SIR_U
+    q[:, :4] = u_scale * rng.standard_normal((B, 4)) + u0
+    if model == "fhn":
+        q[:, 4:6] = 0.5 * rng.standard_normal((B, 2))
+    else:
+        q[:, 4:5] = 1.0 + 0.1 * rng.standard_normal((B, 1))
+    nv = T * S * m.dim_v
+    o = 4 + m.dim_v_0
+    q[:, o:o + nv] = v_scale * rng.standard_normal((B, nv))
+    if noisy:
+        q[:, o + nv:] = rng.standard_normal((B, T))
+    return q
+
+
+def make_case(model, T, S, R, noisy, B, seed, obs_interval=None, gaussian=False):
+    """Random chain states; the data are generated from chain 0 so that chain 0 lies on the manifold
+    (c(q_0) = 0 in every partition).  Returns dict with q [B,Q], x_obs [B,T,X], y [T], sigma, oracle system."""
+    rng = np.random.default_rng(seed)
+    m = em.MODELS[model]
+    if obs_interval is None:
+        obs_interval = 0.2 if model == "fhn" else 0.25
+    sigma = (0.1 if model == "fhn" else 1.0) if noisy else None
+    q = random_q(model, T, S, noisy, B, rng)
+    tmp = c_oracle.OracleSystem(model, obs_interval, S, R, np.zeros(T), sigma=sigma, use_gaussian_splitting=gaussian)
+    xo = np.stack([tmp.generate_x_obs_seq(q[c]) for c in range(B)])
+    y = m.obs_func(xo[0])[:, 0] + (sigma * q[0, -T:] if noisy else 0.0)
+    osys = c_oracle.OracleSystem(model, obs_interval, S, R, y, sigma=sigma, use_gaussian_splitting=gaussian)
+    return dict(model=model, T=T, S=S, R=R, noisy=noisy, B=B, q=q, x_obs=xo, y=y, sigma=sigma,
+                obs_interval=obs_interval, gaussian=gaussian, osys=osys, rng=rng)
+
+
+def make_ctx(case, **kw):
+    from manifold_mcmc_for_diffusions_amd.context import ChmcContext
+    return ChmcContext(case["model"], case["obs_interval"], case["S"], case["R"], case["y"], sigma=case["sigma"],
+                       use_gaussian_splitting=case["gaussian"], num_chains=case["B"], **kw)
+
+
+def check_ops_against_oracle(ctx, case, tol=1e-10):
+    """Every per-op entry point of the C ABI against the C oracle, for every partition; returns max rel errors."""
+    osys, q, xo, B = case["osys"], case["q"], case["x_obs"], case["B"]
+    rng = case["rng"]
+    worst = {}
+
+    def upd(k, a, b):
+        scale = max(1.0, float(np.max(np.abs(b))))
+        worst[k] = max(worst.get(k, 0.0), float(np.max(np.abs(a - b))) / scale)
+
+    for part in range(ctx.num_partition):
+        p = rng.standard_normal((B, ctx.Q))
+        ctx.set_state(q, p, xo, part)
+        c_h = ctx.constr()
+        du_h, dv_h = ctx.jacob_constr_blocks()
+        cC, cD = ctx.chol_gram_blocks()
+        ld = ctx.log_det_sqrt_gram()
+        g = ctx.grad_log_det_sqrt_gram()
+        w = rng.standard_normal((B, ctx.Q))
+        lam = rng.standard_normal((B, ctx.dim_c))
+        Jw, JTl = ctx.lmult_by_jacob_constr(w), ctx.rmult_by_jacob_constr(lam)
+        Gil, nsc = ctx.lmult_by_inv_gram(lam), ctx.normal_space_component(w)
+        for c in range(B):
+            c_o, du_o, dv_o = osys.jacob_constr_blocks(q[c], xo[c], part)
+            cCo, cDo, ldo, go = osys.gram_ops(q[c], xo[c], part)
+            Jwo, JTlo, Gilo, nsco = osys.jacob_products(q[c], xo[c], part, w[c], lam[c])
+            rm = osys.rmax
+            upd("constr", c_h[c], c_o)
+            upd("dc_du", du_h[c], du_o)
+            upd("dc_dv", dv_h[c][:rm], dv_o)
+            if ctx.RM > rm:
+                upd("dc_dv_pad", dv_h[c][rm:], np.zeros_like(dv_h[c][rm:]))
+            upd("chol_C", cC[c], cCo)
+            for b in range(ctx.num_blocks):
+                r = osys.block_info(part, b)["nrows"]
+                upd("chol_D", cD[c][b][:r, :r], cDo[b][:r, :r])
+            upd("log_det", np.array([ld[c]]), np.array([ldo]))
+            upd("grad_log_det", g[c], go)
+            upd("lmult_jacob", Jw[c], Jwo)
+            upd("rmult_jacob", JTl[c], JTlo)
+            upd("inv_gram", Gil[c], Gilo)
+            upd("normal_space", nsc[c], nsco)
+    bad = {k: v for k, v in worst.items() if not v < tol}
+    assert not bad, f"op parity failures (rel err): {bad}; all: {worst}"
+    return worst
+
+
+def check_steps_against_oracle(ctx, case, dts, newton=True, n_steps=1, tol=1e-9, part=0):
+    """Fused leapfrog steps against the C oracle chain by chain, starting from chain 0's on-manifold state with
+    independent momenta."""
+    osys, B = case["osys"], case["B"]
+    rng = case["rng"]
+    qq = np.repeat(case["q"][:1], B, 0)
+    xx = np.repeat(case["x_obs"][:1], B, 0)
+    ctx.set_state(qq, rng.standard_normal((B, ctx.Q)), xx, part)
+    ctx.project_onto_cotangent_space()
+    _, p0, _, _ = ctx.get_state()
+    chains = []
+    for c in range(B):
+        ch = c_oracle.OracleChain(osys)
+        ch.set(qq[c], p0[c], xx[c], part)
+        chains.append(ch)
+    h = ctx.hamiltonian()
+    for c in range(B):
+        assert abs(h[c, 0] - chains[c].hamiltonian()) <= 1e-10 * max(1.0, abs(h[c, 0]))
+    out = []
+    dts = np.broadcast_to(np.asarray(dts, dtype=np.float64), (B,))
+    for _ in range(n_steps):
+        res = ctx.leapfrog_step(dts, newton=newton)
+        q1, p1, _, _ = ctx.get_state()
+        h1 = ctx.hamiltonian()
+        for c in range(B):
+            st, itf, itb, rev = chains[c].step(dts[c], newton=newton)
+            qo, po, _, _ = chains[c].get()
+            assert res["status"][c] == st, (c, res["status"][c], st)
+            assert res["iters_fwd"][c] == itf and (st != 0 or res["iters_bwd"][c] == itb), (c, res, itf, itb)
+            sq, sp = max(1.0, np.abs(qo).max()), max(1.0, np.abs(po).max())
+            assert np.abs(q1[c] - qo).max() <= tol * sq, (c, np.abs(q1[c] - qo).max())
+            assert np.abs(p1[c] - po).max() <= tol * sp, (c, np.abs(p1[c] - po).max())
+            assert abs(h1[c, 0] - chains[c].hamiltonian()) <= 1e-9 * max(1.0, abs(h1[c, 0]))
+            out.append((st, itf, itb))
+    return out

@@ -1,0 +1,93 @@
+"""CPU-side tests of the library's HOST logic (kernel sequencing of csrc/chmc_api.inc, masks, status codes,
+partition tables, padded layouts) through a TEST-ONLY host emulation build (tests/emu): every device functor is
+run in a plain loop.  The emulation library is never loadable through the package (the loader only knows
+libchmc_hip.so); it is injected here explicitly.  The GPU parity tests proper are in test_hip_parity.py."""
+import ctypes
+import os
+import subprocess
+import numpy as np
+import pytest
+from helpers import make_case, make_ctx, check_ops_against_oracle, check_steps_against_oracle
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU = os.path.join(HERE, "emu", "libchmc_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    from manifold_mcmc_for_diffusions_amd import _lib
+    srcs = [os.path.join(HERE, "emu", f) for f in ("chmc_emu.cpp", "backend_emu.h")]
+    csrc = os.path.join(os.path.dirname(HERE), "manifold_mcmc_for_diffusions_amd", "csrc")
+    srcs += [os.path.join(csrc, f) for f in os.listdir(csrc)]
+    if not os.path.exists(EMU) or any(os.path.getmtime(EMU) < os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-I.", "-o", EMU, "chmc_emu.cpp"],
+                              cwd=os.path.join(HERE, "emu"))
+    saved = _lib._LIB
+    _lib._LIB = _lib._bind(ctypes.CDLL(EMU))
+    assert _lib.lib().chmc_backend() == b"emu:host-TEST-ONLY"
+    yield _lib._LIB
+    _lib._LIB = saved
+
+
+CASES = [
+    ("fhn", 6, 4, 2, True, False),
+    ("fhn", 7, 5, 3, False, False),
+    ("fhn", 6, 4, 2, True, True),
+    ("fhn", 5, 4, None, True, False),
+    ("fhn", 12, 10, 5, False, True),
+    ("sir", 5, 6, None, True, False),
+    ("sir", 6, 8, 2, True, False),
+    ("sir", 14, 6, 14, True, False),
+]
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy,gaussian", CASES)
+def test_ops(emu_lib, model, T, S, R, noisy, gaussian):
+    case = make_case(model, T, S, R, noisy, B=3, seed=11, gaussian=gaussian)
+    ctx = make_ctx(case)
+    check_ops_against_oracle(ctx, case)
+    ctx.close()
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy,gaussian", CASES)
+@pytest.mark.parametrize("newton", [True, False])
+def test_steps(emu_lib, model, T, S, R, noisy, gaussian, newton):
+    case = make_case(model, T, S, R, noisy, B=4, seed=12, gaussian=gaussian)
+    ctx = make_ctx(case)
+    check_steps_against_oracle(ctx, case, np.array([0.05, -0.05, 0.1, 0.02]), newton=newton, n_steps=3)
+    ctx.close()
+
+
+def test_failed_and_inactive_chains_keep_state(emu_lib):
+    case = make_case("fhn", 6, 4, 2, True, B=3, seed=13)
+    ctx = make_ctx(case)
+    qq = np.repeat(case["q"][:1], 3, 0)
+    xx = np.repeat(case["x_obs"][:1], 3, 0)
+    ctx.set_state(qq, case["rng"].standard_normal((3, ctx.Q)), xx, 0)
+    ctx.project_onto_cotangent_space()
+    q0, p0, _, _ = ctx.get_state()
+    res = ctx.leapfrog_step(np.array([0.05, 5.0, -0.05]), max_iters=3, active=np.array([1, 1, 0]))
+    q1, p1, _, _ = ctx.get_state()
+    assert res["status"][0] == 0 and res["status"][1] in (1, 2, 3) and res["status"][2] == -1
+    assert np.array_equal(q1[1], q0[1]) and np.array_equal(p1[1], p0[1])
+    assert np.array_equal(q1[2], q0[2]) and np.array_equal(p1[2], p0[2])
+    assert not np.array_equal(q1[0], q0[0])
+    ctx.close()
+
+
+def test_api_misuse_is_reported(emu_lib):
+    from manifold_mcmc_for_diffusions_amd.context import ChmcContext
+    with pytest.raises(RuntimeError, match="sigma"):
+        ChmcContext("fhn", 0.2, 4, 2, np.zeros(6), sigma=0.0)
+    with pytest.raises(RuntimeError, match="not supported"):
+        ChmcContext("fhn", 0.2, 4, None, np.zeros(20), sigma=0.1)  # unpartitioned FHN: 20 rows in one block
+    case = make_case("fhn", 6, 4, 2, True, B=2, seed=1)
+    ctx = make_ctx(case)
+    with pytest.raises(ValueError):
+        ctx.set_state(case["q"][:1], None, case["x_obs"], 0)
+    with pytest.raises(RuntimeError, match="partition"):
+        ctx.set_state(case["q"], None, case["x_obs"], 5)
+    with pytest.raises(RuntimeError, match="n_inner_step"):
+        ctx.set_state(case["q"], None, case["x_obs"], 0)
+        ctx.leapfrog_step(0.1, n_inner_step=2)
+    ctx.close()

@@ -1,0 +1,132 @@
+"""GPU parity tests: the HIP library (through its C ABI) against the C oracle on identical seeded inputs.
+
+Tolerances: the path is fp64 end to end and both sides use the same generated model arithmetic, so the only
+differences are summation order (Gram / dot-product reductions) and FMA contraction; per-op results must agree
+to 1e-10 relative (inf-norm), single leapfrog steps to 1e-9 relative at identical Newton iteration counts
+(SURVEY.md section 8c)."""
+import numpy as np
+import pytest
+from helpers import make_case, make_ctx, check_ops_against_oracle, check_steps_against_oracle
+
+pytestmark = pytest.mark.gpu
+
+SMALL = [
+    # model, T, S, R, noisy, gaussian
+    ("fhn", 6, 4, 2, True, False),
+    ("fhn", 7, 5, 3, False, False),
+    ("fhn", 6, 4, 2, True, True),
+    ("fhn", 5, 4, None, True, False),
+    ("fhn", 12, 10, 5, True, False),
+    ("fhn", 12, 10, 5, False, True),
+    ("sir", 5, 6, None, True, False),
+    ("sir", 6, 8, 2, True, False),
+    ("sir", 14, 6, 14, True, False),
+]
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy,gaussian", SMALL)
+def test_ops_small(model, T, S, R, noisy, gaussian):
+    case = make_case(model, T, S, R, noisy, B=3, seed=11, gaussian=gaussian)
+    ctx = make_ctx(case)
+    assert ctx.L.chmc_backend() == b"hip:gfx950"
+    check_ops_against_oracle(ctx, case)
+    ctx.close()
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy,gaussian", SMALL)
+@pytest.mark.parametrize("newton", [True, False])
+def test_steps_small(model, T, S, R, noisy, gaussian, newton):
+    case = make_case(model, T, S, R, noisy, B=4, seed=12, gaussian=gaussian)
+    ctx = make_ctx(case)
+    dts = np.array([0.05, -0.05, 0.1, 0.02])
+    check_steps_against_oracle(ctx, case, dts, newton=newton, n_steps=3)
+    ctx.close()
+
+
+def test_failed_chains_keep_state():
+    case = make_case("fhn", 6, 4, 2, True, B=3, seed=13)
+    ctx = make_ctx(case)
+    dts = np.array([0.05, 5.0, -0.05])  # the middle chain cannot converge with max_iters=3
+    qq = np.repeat(case["q"][:1], 3, 0)
+    xx = np.repeat(case["x_obs"][:1], 3, 0)
+    ctx.set_state(qq, case["rng"].standard_normal((3, ctx.Q)), xx, 0)
+    ctx.project_onto_cotangent_space()
+    q0, p0, _, _ = ctx.get_state()
+    res = ctx.leapfrog_step(dts, max_iters=3, active=np.array([1, 1, 0]))
+    q1, p1, _, _ = ctx.get_state()
+    assert res["status"][0] == 0 and res["status"][1] in (1, 2, 3) and res["status"][2] == -1
+    assert np.array_equal(q1[1], q0[1]) and np.array_equal(p1[1], p0[1])
+    assert np.array_equal(q1[2], q0[2]) and np.array_equal(p1[2], p0[2])
+    assert not np.array_equal(q1[0], q0[0])
+    ctx.close()
+
+
+def test_baseline_config1_fhn_noisy_s50():
+    """BASELINE.json configs[0]: FHN noisy-obs, 50 inter-obs steps (T=100, R=5), here 2 chains."""
+    case = make_case("fhn", 100, 50, 5, True, B=2, seed=14)
+    ctx = make_ctx(case)
+    check_ops_against_oracle(ctx, case)
+    check_steps_against_oracle(ctx, case, np.array([0.05, -0.05]), n_steps=2)
+    ctx.close()
+
+
+def test_baseline_config2_size_fhn_noisy_s400():
+    """Full-size shape of BASELINE.json configs[1] (Q = 80106), 2 chains, one step against the oracle."""
+    case = make_case("fhn", 100, 400, 5, True, B=2, seed=15)
+    ctx = make_ctx(case)
+    assert ctx.Q == 80106 and ctx.C == [138, 140] and ctx.K == [20, 21]
+    check_steps_against_oracle(ctx, case, np.array([0.05, -0.05]), n_steps=1)
+    ctx.close()
+
+
+def test_baseline_config3_size_fhn_noiseless_s400():
+    case = make_case("fhn", 100, 400, 5, False, B=2, seed=16)
+    ctx = make_ctx(case)
+    assert ctx.Q == 80006 and ctx.C == [119, 120]
+    check_steps_against_oracle(ctx, case, np.array([0.05, -0.05]), n_steps=1)
+    ctx.close()
+
+
+def test_size_independent_properties_full_size():
+    """At full size: after a successful step |c|_inf < ctol, J p = 0 (momentum tangent), and a step followed by a
+    direction flip returns to the start (reversibility, tolerance 2e-8 as reverse_check_tol)."""
+    case = make_case("fhn", 100, 400, 5, True, B=4, seed=17)
+    ctx = make_ctx(case)
+    B = 4
+    qq = np.repeat(case["q"][:1], B, 0)
+    xx = np.repeat(case["x_obs"][:1], B, 0)
+    ctx.set_state(qq, case["rng"].standard_normal((B, ctx.Q)), xx, 0)
+    ctx.project_onto_cotangent_space()
+    q0, p0, _, _ = ctx.get_state()
+    dt = np.array([0.05, 0.03, -0.04, 0.02])
+    res = ctx.leapfrog_step(dt)
+    assert (res["status"] == 0).all()
+    assert np.abs(ctx.constr()).max() < 1e-9
+    q1, p1, _, _ = ctx.get_state()
+    Jp = ctx.lmult_by_jacob_constr(p1)
+    assert np.abs(Jp).max() < 1e-9 * np.abs(p1).max() * np.sqrt(ctx.Q)
+    res2 = ctx.leapfrog_step(-dt)
+    assert (res2["status"] == 0).all()
+    q2, p2, _, _ = ctx.get_state()
+    assert np.abs(q2 - q0).max() < 2e-8
+    assert np.abs(p2 - p0).max() < 1e-6
+    ctx.close()
+
+
+def test_switch_partition_matches_oracle():
+    from oracle import c_oracle
+    case = make_case("fhn", 12, 10, 5, True, B=2, seed=18)
+    ctx = make_ctx(case)
+    ctx.set_state(case["q"], None, case["x_obs"], 0)
+    ctx.switch_partition()
+    _, _, xo, part = ctx.get_state()
+    assert part == 1
+    for c in range(2):
+        ch = c_oracle.OracleChain(case["osys"])
+        ch.set(case["q"][c], None, case["x_obs"][c], 0)
+        ch.switch_partition()
+        _, _, xo_o, part_o = ch.get()
+        assert part_o == 1
+        assert np.abs(xo[c] - xo_o).max() < 1e-12
+        assert abs(ctx.log_det_sqrt_gram()[c] - ch.log_det()) < 1e-10
+    ctx.close()
