@@ -112,6 +112,14 @@ int chmc_leapfrog_step(chmc_ctx* ctx, const double* dt, const int* active, int n
  * grad_log_det_sqrt_gram, leapfrog_step calls, newton iteration launches, 0} (cf. _call_counts, :1451-1461) */
 int chmc_get_counters(const chmc_ctx* ctx, long long* out8);
 
+/* ---- measurement: HIP events recorded on the library's own stream around every kernel launch ------------- */
+/* kernel classes: 0 other, 1 newton_blk (constr + Jacobian + Gram/LU of a Newton iteration), 2 state_blk
+ * (Jacobian store + Gram + Cholesky), 3 grad_log_det_blk, 4 update (J^T lambda column pass), 5 solve_chain,
+ * 6 jacob_vec (J w), 7 constr (forward scan only), 8 element-wise, 9 sym_blk */
+#define CHMC_NUM_KERNEL_CLASSES 10
+int chmc_profile_enable(int on);                        /* start / stop recording (resets the accumulators) */
+int chmc_profile_get(double* ms, long long* launches);  /* [CHMC_NUM_KERNEL_CLASSES] each; synchronises */
+
 #ifdef __cplusplus
 }
 #endif

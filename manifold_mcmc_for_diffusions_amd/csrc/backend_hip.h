@@ -76,13 +76,109 @@ __global__ void __launch_bounds__(256) k_run(F f, int n) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid < n) f(tid);
 }
+// optional per-launch timing with HIP events on g_stream (bench.py's roofline figure)
+#include <vector>
+struct ProfRec {
+  hipEvent_t a, b;
+  int cls;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_pending;
+static std::vector<hipEvent_t> g_prof_pool;
+static double g_prof_ms[16];
+static long long g_prof_n[16];
+static hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  note(hipEventCreate(&e));
+  return e;
+}
+static void prof_drain() {
+  if (g_prof_pending.empty()) return;
+  note(hipStreamSynchronize(g_stream));
+  for (auto& r : g_prof_pending) {
+    float ms = 0.f;
+    note(hipEventElapsedTime(&ms, r.a, r.b));
+    g_prof_ms[r.cls] += ms;
+    g_prof_n[r.cls] += 1;
+    g_prof_pool.push_back(r.a);
+    g_prof_pool.push_back(r.b);
+  }
+  g_prof_pending.clear();
+}
 template <class F>
-static void launch(F f, long n) {
+static void launch(F f, long n, int cls = 0) {
   if (n <= 0) return;
   const int bs = n >= 65536 ? 256 : 64;
   const unsigned grid = (unsigned)((n + bs - 1) / bs);
+  ProfRec r;
+  if (g_prof_on) {
+    r.a = prof_event(), r.b = prof_event(), r.cls = cls;
+    note(hipEventRecord(r.a, g_stream));
+  }
   hipLaunchKernelGGL(k_run<F>, dim3(grid), dim3(bs), 0, g_stream, f, (int)n);
   note(hipGetLastError());
+  if (g_prof_on) {
+    note(hipEventRecord(r.b, g_stream));
+    g_prof_pending.push_back(r);
+    if (g_prof_pending.size() > 4096) prof_drain();
+  }
+}
+// column-max launch: grid (ceil(ncol / 256), B); f(c, col) returns a bit pattern that is max-reduced per chain
+template <class F>
+__global__ void __launch_bounds__(256) k_colmax(F f, int ncol) {
+  const int c = blockIdx.y;
+  if (!f.active(c)) return;  // uniform per workgroup
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long v = 0ULL;
+  if (col < ncol) v = f(c, col);
+  unsigned long long* tgt = f.red(c);
+  if (!tgt) return;
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  __shared__ unsigned long long sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 4; ++i) v = sm[i] > v ? sm[i] : v;
+    if (v) atomicMax(tgt, v);
+  }
+}
+template <class F>
+static void launch_colmax(F f, int ncol, int B, int cls = 0) {
+  if (ncol <= 0 || B <= 0) return;
+  ProfRec r;
+  if (g_prof_on) {
+    r.a = prof_event(), r.b = prof_event(), r.cls = cls;
+    note(hipEventRecord(r.a, g_stream));
+  }
+  hipLaunchKernelGGL(k_colmax<F>, dim3((unsigned)((ncol + 255) / 256), (unsigned)B), dim3(256), 0, g_stream, f, ncol);
+  note(hipGetLastError());
+  if (g_prof_on) {
+    note(hipEventRecord(r.b, g_stream));
+    g_prof_pending.push_back(r);
+    if (g_prof_pending.size() > 4096) prof_drain();
+  }
+}
+extern "C" int chmc_profile_enable(int on) {
+  if (g_stream) prof_drain();
+  for (int i = 0; i < 16; ++i) g_prof_ms[i] = 0.0, g_prof_n[i] = 0;
+  g_prof_on = on != 0;
+  return 0;
+}
+extern "C" int chmc_profile_get(double* ms, long long* launches) {
+  if (g_stream) prof_drain();
+  for (int i = 0; i < 10; ++i) {
+    if (ms) ms[i] = g_prof_ms[i];
+    if (launches) launches[i] = g_prof_n[i];
+  }
+  return 0;
 }
 // HIP events on the library's stream (used by bench.py to time kernels where they are launched)
 extern "C" void* chmc_stream(void) { return (void*)g_stream; }

@@ -1009,7 +1009,9 @@ struct KSolveChain {
   }
 };
 
-// Column-parallel part of J^T lambda (rmult_by_jacob_constr :879-913) fused with its consumer.
+// Column-parallel part of J^T lambda (rmult_by_jacob_constr :879-913) fused with its consumer; a "column max"
+// kernel: work item (chain c, column col), the returned bit pattern is max-reduced per chain into *red(c)
+// by the launcher (wave shuffle + LDS, one atomic per workgroup -- 2e7 same-address atomics serialise).
 //  TGT 0: q -= d, mu += d, ndq = max |d|     TGT 1: p -= d     TGT 2: out = d (work.pb, all columns incl. u)
 template <int RM, int TGT>
 struct KUpdate {
@@ -1017,10 +1019,9 @@ struct KUpdate {
   Slots sl;
   Work w;
   int which, qsel, psel;
-  CHMC_HD void operator()(int tid) const {
-    const int c = tid / sy.NCOL;
-    const int col = tid - c * sy.NCOL;
-    if (TGT == 0 ? !w.nw[c] : !w.ok[c]) return;
+  CHMC_HD bool active(int c) const { return TGT == 0 ? w.nw[c] != 0 : w.ok[c] != 0; }
+  CHMC_HD unsigned long long* red(int c) const { return TGT == 0 ? &w.ndq[c] : nullptr; }
+  CHMC_HD unsigned long long operator()(int c, int col) const {
     const int s = sl.cur[c] ^ which;
     double d;
     if (col < sy.NV) {
@@ -1042,13 +1043,14 @@ struct KUpdate {
       double* q = qsel ? w.qb : sl.q[s ^ 1];
       q[qi] -= d;
       w.mu[qi] += d;
-      atomic_max_u64(&w.ndq[c], absbits(d));
+      return absbits(d);
     } else if (TGT == 1) {
       double* p = psel == 0 ? sl.p[s] : psel == 1 ? w.pb : sl.p[s ^ 1];
       p[qi] -= d;
     } else {
       w.pb[qi] = d;
     }
+    return 0ULL;
   }
 };
 
@@ -1186,16 +1188,16 @@ struct KMomFix {
     sl.p[s][tid] -= sc * w.mu[tid];
   }
 };
-// reverse check distance max |q_back - q_start| (mici maximum_norm)
+// reverse check distance max |q_back - q_start| (mici maximum_norm); column-max kernel over all Q components
 struct KRevDiff {
   Sys sy;
   Slots sl;
   Work w;
-  CHMC_HD void operator()(int tid) const {
-    const int c = tid / sy.Q;
-    if (!w.ok[c]) return;
-    const int s = sl.cur[c];
-    atomic_max_u64(&w.rev[c], absbits(w.qb[tid] - sl.q[s][tid]));
+  CHMC_HD bool active(int c) const { return w.ok[c] != 0; }
+  CHMC_HD unsigned long long* red(int c) const { return &w.rev[c]; }
+  CHMC_HD unsigned long long operator()(int c, int col) const {
+    const size_t i = (size_t)c * sy.Q + col;
+    return absbits(w.qb[i] - sl.q[sl.cur[c]][i]);
   }
 };
 struct KRevCheck {

@@ -1,0 +1,321 @@
+"""Mici System / chain-state / projection-solver surface of the reference, backed by the HIP library.
+
+Same names, argument order and error behaviour as `sde.mici_extensions` (reference file:line cited per item);
+the differences a C ABI forces are:
+  * the four model callables must be the model handles of `example_models` (they select compiled device code);
+  * every array may carry a leading chain axis B (`num_chains`); with B == 1 plain reference shapes are accepted
+    and returned, and numerical failures raise the reference's exceptions; with B > 1 they are reported per chain;
+  * `jacob_constr_blocks` returns the library's layouts (dc_du [C, U], dc_dv row-slot [RM, NV], dc_dn = sigma).
+The state an operation refers to is made resident on the device on demand and cached there, which plays the role
+of Mici's `cache_in_state` memoisation (:1151-1184).
+"""
+import itertools
+from numbers import Number
+import numpy as np
+from .context import ChmcContext
+from .errors import ConvergenceError
+from .example_models import ModelHandle
+
+_tokens = itertools.count(1)
+
+
+class IdentityMatrix:
+    """Stand-in for mici.matrices.IdentityMatrix (the only metric the device path implements)."""
+
+    def __matmul__(self, other):
+        return other
+
+    def __rmatmul__(self, other):
+        return other
+
+    @property
+    def inv(self):
+        return self
+
+    @property
+    def sqrt(self):
+        return self
+
+
+class ScaledIdentity:
+    """`scalar * IdentityMatrix()` as returned by dh2_flow_dmom (:1233-1238)."""
+
+    def __init__(self, scalar):
+        self.scalar = scalar
+
+    def __matmul__(self, other):
+        s = np.asarray(self.scalar)
+        return (s[..., None] if s.ndim else s) * other
+
+
+def _is_identity(metric):
+    return metric is None or isinstance(metric, IdentityMatrix) or type(metric).__name__ == "IdentityMatrix"
+
+
+class ConditionedDiffusionHamiltonianState:
+    """sde/mici_extensions.py:1285-1320.  Assigning `pos`, `x_obs_seq` or `partition` invalidates everything cached
+    for the state (the dependency sets of :1151-1176); copies share the call-count dictionary like Mici's."""
+
+    _deps = ("pos", "x_obs_seq", "partition")
+
+    def __init__(self, pos, x_obs_seq, partition=0, mom=None, dir=1, _call_counts=None, _dependencies=None,
+                 _cache=None, _read_only=False):
+        object.__setattr__(self, "_call_counts", {} if _call_counts is None else _call_counts)
+        object.__setattr__(self, "_token", next(_tokens))
+        object.__setattr__(self, "_mom_token", next(_tokens))
+        self.pos = np.array(pos, dtype=np.float64)
+        self.x_obs_seq = np.array(x_obs_seq, dtype=np.float64)
+        self.partition = int(partition)
+        self.mom = None if mom is None else np.array(mom, dtype=np.float64)
+        self.dir = dir
+
+    def __setattr__(self, k, v):
+        if k in self._deps:
+            object.__setattr__(self, "_token", next(_tokens))
+        elif k == "mom":
+            object.__setattr__(self, "_mom_token", next(_tokens))
+        object.__setattr__(self, k, v)
+
+    def copy(self):
+        new = object.__new__(type(self))
+        for k, v in self.__dict__.items():
+            object.__setattr__(new, k, v.copy() if isinstance(v, np.ndarray) else v)
+        object.__setattr__(new, "_call_counts", self._call_counts)
+        return new
+
+
+class ConditionedDiffusionConstrainedSystem:
+    """sde/mici_extensions.py:208-1259."""
+
+    def __init__(self, obs_interval, num_steps_per_obs, num_obs_per_subseq, y_seq, dim_u, dim_x, dim_v, forward_func,
+                 generate_x_0, generate_z, obs_func, generate_σ=None, use_gaussian_splitting=False, metric=None,
+                 dim_v_0=None, *, num_chains=1, device=0):
+        handles = (forward_func, generate_x_0, generate_z, obs_func)
+        if not all(isinstance(h, ModelHandle) for h in handles) or len({h.model for h in handles}) != 1:
+            raise TypeError("forward_func, generate_x_0, generate_z and obs_func must be the handles of one model of "
+                            "manifold_mcmc_for_diffusions_amd.example_models (device code is selected by model)")
+        model = forward_func.model
+        if use_gaussian_splitting and not _is_identity(metric):  # :293-300
+            raise ValueError("Only identity matrix metric can be used with Gaussian splitting")
+        if not _is_identity(metric):  # :305-315 (block metrics are not implemented on the device path)
+            raise NotImplementedError("Only the identity metric is implemented on the device path.")
+        if generate_σ is not None and not isinstance(generate_σ, Number):
+            raise NotImplementedError("Variable observation noise (callable generate_σ) is not implemented; pass the "
+                                      "fixed standard deviation as a number or None for noiseless observations.")
+        y_seq = np.asarray(y_seq, dtype=np.float64)
+        if y_seq.ndim != 2 or y_seq.shape[1] != model.dim_y:
+            raise ValueError(f"y_seq must have shape (num_obs, {model.dim_y})")
+        dim_v_0 = dim_x if dim_v_0 is None else dim_v_0
+        if (dim_u, dim_x, dim_v, dim_v_0) != (model.dim_z, model.dim_x, model.dim_v, model.dim_v_0):
+            raise ValueError("dim_u / dim_x / dim_v / dim_v_0 do not match the model")
+        self.metric = IdentityMatrix()
+        self.use_gaussian_splitting = bool(use_gaussian_splitting)
+        self.model = model
+        self.ctx = ChmcContext(model.name, obs_interval, num_steps_per_obs, num_obs_per_subseq, y_seq[:, 0],
+                               sigma=None if generate_σ is None else float(generate_σ),
+                               use_gaussian_splitting=use_gaussian_splitting, num_chains=num_chains, device=device)
+        self.num_chains = num_chains
+        self.num_partition = self.ctx.num_partition  # :362
+        δ = obs_interval / num_steps_per_obs
+        self.model_dict = {  # :363-377
+            "dim_u": dim_u, "dim_v": dim_v, "dim_v_0": dim_v_0, "dim_y": model.dim_y, "num_obs": y_seq.shape[0],
+            "num_steps_per_obs": num_steps_per_obs, "δ": δ, "generate_z": generate_z, "generate_x_0": generate_x_0,
+            "generate_σ": generate_σ, "forward_func": forward_func, "obs_func": obs_func, "y_seq": y_seq,
+        }
+        self.y_subseqs = [[y_seq[b["obs0"]:b["obs0"] + b["nobs"]] for b in blocks] for blocks in self.ctx.blocks]
+        self._resident = None
+        self._resident_mom = None
+
+    # ---- residency (plays the role of cache_in_state)
+    def _b(self, a, tail):
+        a = np.asarray(a, dtype=np.float64)
+        return a.reshape((self.num_chains,) + tail)
+
+    def _out(self, a, state):
+        return a[0] if np.ndim(state.pos) == 1 else a
+
+    def _sync(self, state, mom=False):
+        c = self.ctx
+        if self._resident != state._token:
+            c.set_state(self._b(state.pos, (c.Q,)), None if state.mom is None else self._b(state.mom, (c.Q,)),
+                        self._b(state.x_obs_seq, (c.T, c.X)), state.partition)
+            self._resident, self._resident_mom = state._token, state._mom_token
+            for k in ("jacob_constr_blocks", "chol_gram_blocks", "log_det_sqrt_gram", "grad_log_det_sqrt_gram"):
+                state._call_counts[k] = state._call_counts.get(k, 0) + 1
+        elif mom and self._resident_mom != state._mom_token and state.mom is not None:
+            c.set_momentum(self._b(state.mom, (c.Q,)))
+            self._resident_mom = state._mom_token
+
+    def _adopt(self, state):
+        """The device now holds `state` (after a device-side update written back into it)."""
+        self._resident, self._resident_mom = state._token, state._mom_token
+
+    # ---- System methods
+    def constr(self, state):  # :1151-1155
+        self._sync(state)
+        state._call_counts["constr"] = state._call_counts.get("constr", 0) + 1
+        return self._out(self.ctx.constr(), state)
+
+    def jacob_constr_blocks(self, state):  # :1157-1161
+        self._sync(state)
+        du, dv = self.ctx.jacob_constr_blocks()
+        dn = None if self.ctx.sigma is None else self.ctx.sigma
+        return self._out(du, state), self._out(dv, state), dn
+
+    def chol_gram_blocks(self, state):  # :1163-1167
+        self._sync(state)
+        cC, cD = self.ctx.chol_gram_blocks()
+        return self._out(cC, state), self._out(cD, state)
+
+    def log_det_sqrt_gram(self, state):  # :1169-1171
+        self._sync(state)
+        ld = self.ctx.log_det_sqrt_gram()
+        return float(ld[0]) if np.ndim(state.pos) == 1 else ld
+
+    def grad_log_det_sqrt_gram(self, state):  # :1173-1184
+        self._sync(state)
+        return self._out(self.ctx.grad_log_det_sqrt_gram(), state)
+
+    def neg_log_dens(self, state):  # standard_normal_neg_log_dens :56-58
+        return 0.5 * np.sum(state.pos ** 2, -1)
+
+    def grad_neg_log_dens(self, state):  # standard_normal_grad_neg_log_dens :61-63
+        return state.pos
+
+    def h1(self, state):  # :1186-1190
+        if self.use_gaussian_splitting:
+            return self.log_det_sqrt_gram(state)
+        return self.neg_log_dens(state) + self.log_det_sqrt_gram(state)
+
+    def dh1_dpos(self, state):  # :1192-1196
+        if self.use_gaussian_splitting:
+            return self.grad_log_det_sqrt_gram(state)
+        return self.grad_neg_log_dens(state) + self.grad_log_det_sqrt_gram(state)
+
+    def h2(self, state):  # :1198-1202
+        if self.use_gaussian_splitting:
+            return 0.5 * np.sum(state.pos ** 2, -1) + 0.5 * np.sum(state.mom ** 2, -1)
+        return 0.5 * np.sum(state.mom ** 2, -1)
+
+    def h(self, state):
+        return self.h1(state) + self.h2(state)
+
+    def dh2_dmom(self, state):  # :1204-1208
+        return state.mom
+
+    def dh_dmom(self, state):
+        return self.dh2_dmom(state)
+
+    def dh2_dpos(self, state):  # :1210-1214
+        return state.pos if self.use_gaussian_splitting else 0 * state.pos
+
+    def dh_dpos(self, state):  # :1216-1220
+        if self.use_gaussian_splitting:
+            return self.dh1_dpos(state) + self.dh2_dpos(state)
+        return self.dh1_dpos(state)
+
+    def h1_flow(self, state, dt):  # mici System.h1_flow
+        state.mom = state.mom - np.asarray(dt)[..., None] * self.dh1_dpos(state) if np.ndim(dt) else \
+            state.mom - dt * self.dh1_dpos(state)
+
+    def h2_flow(self, state, dt):  # :1222-1231
+        dtb = np.asarray(dt)[..., None] if np.ndim(dt) else dt
+        if self.use_gaussian_splitting:
+            sin_dt, cos_dt = np.sin(dtb), np.cos(dtb)
+            pos = state.pos.copy()
+            state.pos = state.pos * cos_dt + sin_dt * state.mom
+            state.mom = state.mom * cos_dt - sin_dt * pos
+        else:
+            state.pos = state.pos + dtb * self.dh2_dmom(state)
+
+    def dh2_flow_dmom(self, dt):  # :1233-1238
+        if self.use_gaussian_splitting:
+            return ScaledIdentity(np.sin(dt)), ScaledIdentity(np.cos(dt))
+        return ScaledIdentity(dt), IdentityMatrix()
+
+    def update_x_obs_seq(self, state):  # :1240-1241
+        self._sync(state)
+        self.ctx.update_x_obs_seq()
+        _, _, xo, _ = self.ctx.get_state(want_p=False)
+        state.x_obs_seq = xo[0] if np.ndim(state.pos) == 1 else xo
+        # x_obs_seq changed: the device caches (J, factors, gradient) are stale until the next _sync
+
+    def normal_space_component(self, state, vct):  # :1243-1250
+        self._sync(state)
+        return self._out(self.ctx.normal_space_component(self._b(vct, (self.ctx.Q,))), state)
+
+    def project_onto_cotangent_space(self, mom, state):  # :1252-1254
+        mom -= self.normal_space_component(state, mom)
+        return mom
+
+    def sample_momentum(self, state, rng):  # :1256-1259
+        mom = rng.standard_normal(state.pos.shape)
+        return self.project_onto_cotangent_space(mom, state)
+
+
+class SwitchPartitionTransition:
+    """sde/mici_extensions.py:1262-1282"""
+
+    state_variables = {"partition", "x_obs_seq"}
+    statistic_types = None
+
+    def __init__(self, system):
+        self.system = system
+        self.num_partition = system.num_partition
+
+    def sample(self, state, rng=None):
+        state.partition = (state.partition + 1) % self.num_partition
+        self.system.update_x_obs_seq(state)
+        return state, None
+
+
+def _solve_projection(newton, state, state_prev, dt, system, constraint_tol, position_tol, divergence_tol, max_iters):
+    c = system.ctx
+    system._sync(state_prev)  # J(state_prev) (+ Cholesky factors for quasi-Newton) resident / cached
+    res = c.project(system._b(state.pos, (c.Q,)), dt, newton=newton, constraint_tol=constraint_tol,
+                    position_tol=position_tol, divergence_tol=divergence_tol, max_iters=max_iters)
+    i = res["iters"]
+    cc = state._call_counts  # :1382-1387, :1451-1461
+    for k in (("constr", "jacob_constr_blocks", "lu_jacob_product_blocks") if newton else ("constr",)):
+        cc[k] = cc.get(k, 0) + int(i.sum())
+    _, dh2_flow_mom_dmom = system.dh2_flow_dmom(dt)
+    ok = res["status"] == 0
+    single = np.ndim(state.pos) == 1
+    state.last_projection = res
+    if ok.all():
+        state.pos = res["q"][0] if single else res["q"]
+        if state.mom is not None:
+            state.mom = state.mom - dh2_flow_mom_dmom @ (res["mu"][0] if single else res["mu"])
+        return state
+    name = "Newton" if newton else "Quasi-Newton"
+    bad = int(np.flatnonzero(~ok)[0])
+    err, ndq, it = float(res["err"][bad]), float(res["norm_dq"][bad]), int(i[bad])
+    where = "" if single else f" (chain {bad}; statuses {res['status'].tolist()})"
+    if res["status"][bad] == 2:  # :1393-1397, :1467-1471
+        raise ConvergenceError(f"{name} iteration diverged on iteration {it}. Last |c|={err:.1e}, |δq|={ndq}.{where}")
+    raise ConvergenceError(f"{name} iteration did not converge. Last |c|={err:.1e}, |δq|={ndq}.{where}")  # :1398-1402
+
+
+def jitted_solve_projection_onto_manifold_quasi_newton(state, state_prev, dt, system, constraint_tol=1e-8,
+                                                       position_tol=1e-8, divergence_tol=1e10, max_iters=50):
+    """sde/mici_extensions.py:1323-1402 (symmetric quasi-Newton retraction)."""
+    return _solve_projection(False, state, state_prev, dt, system, constraint_tol, position_tol, divergence_tol,
+                             max_iters)
+
+
+def jitted_solve_projection_onto_manifold_newton(state, state_prev, dt, system, constraint_tol=1e-8,
+                                                 position_tol=1e-8, divergence_tol=1e10, max_iters=50):
+    """sde/mici_extensions.py:1405-1476 (full Newton retraction)."""
+    return _solve_projection(True, state, state_prev, dt, system, constraint_tol, position_tol, divergence_tol,
+                             max_iters)
+
+
+def find_initial_state_by_linear_interpolation(system, rng, generate_x_obs_seq_init, u=None, v_0=None, **model_dict):
+    """sde/mici_extensions.py:1479-1547 for one chain (num_chains == 1 systems)."""
+    from .init import find_initial_state_by_linear_interpolation as _find
+    md = system.model_dict if not model_dict else model_dict
+    q, x_obs_seq = _find(system.model, md["δ"] * md["num_steps_per_obs"], md["num_steps_per_obs"], md["y_seq"], rng,
+                         generate_x_obs_seq_init, md["generate_σ"] is not None, u=u, v_0=v_0)
+    state = ConditionedDiffusionHamiltonianState(pos=q, x_obs_seq=x_obs_seq)
+    state.mom = system.sample_momentum(state, rng)
+    return state

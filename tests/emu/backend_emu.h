@@ -14,6 +14,29 @@ static void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
 static void d2d(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
 static int dev_sync() { return 0; }
 template <class F>
-static void launch(F f, long n) {
+static void launch(F f, long n, int cls = 0) {
+  (void)cls;
   for (long t = 0; t < n; ++t) f((int)t);
+}
+template <class F>
+static void launch_colmax(F f, int ncol, int B, int cls = 0) {
+  (void)cls;
+  for (int c = 0; c < B; ++c) {
+    if (!f.active(c)) continue;
+    unsigned long long v = 0ULL;
+    for (int col = 0; col < ncol; ++col) {
+      const unsigned long long o = f(c, col);
+      v = o > v ? o : v;
+    }
+    unsigned long long* t = f.red(c);
+    if (t && v > *t) *t = v;
+  }
+}
+extern "C" int chmc_profile_enable(int) { return 0; }
+extern "C" int chmc_profile_get(double* ms, long long* n) {
+  for (int i = 0; i < 10; ++i) {
+    if (ms) ms[i] = 0.0;
+    if (n) n[i] = 0;
+  }
+  return 0;
 }
