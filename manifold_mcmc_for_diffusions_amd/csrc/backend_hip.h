@@ -166,6 +166,23 @@ static void launch_colmax(F f, int ncol, int B, int cls = 0) {
     if (g_prof_pending.size() > 4096) prof_drain();
   }
 }
+// wave kernels (chmc_wave.h): 4 wavefronts per 256-thread workgroup, one (chain, block) per wavefront
+template <class K, class... Args>
+static void launch_wave(K kern, long nwaves, int cls, Args... args) {
+  if (nwaves <= 0) return;
+  ProfRec r;
+  if (g_prof_on) {
+    r.a = prof_event(), r.b = prof_event(), r.cls = cls;
+    note(hipEventRecord(r.a, g_stream));
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, g_stream, args...);
+  note(hipGetLastError());
+  if (g_prof_on) {
+    note(hipEventRecord(r.b, g_stream));
+    g_prof_pending.push_back(r);
+    if (g_prof_pending.size() > 4096) prof_drain();
+  }
+}
 extern "C" int chmc_profile_enable(int on) {
   if (g_stream) prof_drain();
   for (int i = 0; i < 16; ++i) g_prof_ms[i] = 0.0, g_prof_n[i] = 0;

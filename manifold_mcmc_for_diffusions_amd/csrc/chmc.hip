@@ -5,5 +5,7 @@
 #define CHMC_HD __host__ __device__
 #define CHMC_BACKEND_NAME "hip:gfx950"
 #define CHMC_BACKEND_HEADER "backend_hip.h"
+#define CHMC_WAVE_KERNELS 1
 #include "chmc_core.h"
+#include "chmc_wave.h"
 #include "chmc_api.inc"

@@ -31,6 +31,8 @@
 
 namespace chmc {
 
+#define CHMC_Q_PAD 64  // doubles of slack after every [B][Q] position buffer (see fwd_block)
+
 struct BlockDesc {
   int obs0, nobs, first, last;
   int row0, nrows, ny;
@@ -80,6 +82,15 @@ struct Work {
   double* vin;      // [B][Q]        generic input vector (per-op API)
   double* Xd;       // [B][T*S][RM][X] tangents for grad log det
   double* gup;      // [B][Kmax][U]
+  double* Dw;       // [B][Kmax][RM][RM] Gram block of the current evaluation (wave kernels -> factor kernels)
+  double* JuL;      // [B][Kmax][RM][U]  dc/du rows of the current Newton iterate
+  double* zbP;      // [B][Kmax][RM][Z]  dc/dz rows (before the generate_z chain rule) of the last state evaluation
+  double* gMb;      // [B][Kmax][RM][RM] (G^-1)_bb
+  double* gzd;      // [B][Kmax][RM][Z]  generate_z'(u) (G^-1 dc/du)_i
+  double* gWu;      // [B][Kmax][RM][U]  rows of G^-1 dc/du
+  double* gxdt;     // [B][Kmax][RM][X]  tangents at the rows' terminal times
+  double* sdt;      // [B] sin(dt)
+  double* cdt;      // [B] cos(dt)
   double* err;      // [B]
   unsigned long long* ndq;  // [B] bit pattern of max |dq|
   unsigned long long* rev;  // [B] bit pattern of reverse-check distance
@@ -92,6 +103,13 @@ struct Work {
   int* nstat;       // [B] status of last projection
   int* n_active;    // [1]
 };
+
+// slot selection as an explicit select: indexing the by-value kernel-argument pointer pairs with a run-time slot
+// makes the compiler spill the whole argument block to scratch
+template <class T_>
+CHMC_HD inline T_* pick(T_* const (&a)[2], int s) {
+  return s ? a[1] : a[0];
+}
 
 CHMC_HD inline unsigned long long dbits(double x) {
   union { double d; unsigned long long u; } c;
@@ -255,10 +273,12 @@ struct ChainConsts {
 
 // One block of `constr` (:473-519): generate_y_bar (:399-411) minus y_bar (:447-470).
 // traj (may be null) receives nsteps+1 states; cp receives RM padded constraint values.
+// The recursion is inherently sequential; the noise increments of the next 8 steps are loaded while the current
+// 8 are integrated so that the dependent arithmetic chain, not memory latency, paces the scan.
 template <class M, int RM>
 CHMC_HD inline void fwd_block(const Sys& sy, const BlockDesc& bd, const ChainConsts<M>& cc, const double* q,
                               const double* xobs, double* traj, double* cp) {
-  constexpr int X = M::X, V = M::V;
+  constexpr int X = M::X, V = M::V, PF = 8;
   double x[X], xn[X];
   const double* vb = q + sy.U;
   if (bd.first) {
@@ -269,22 +289,41 @@ CHMC_HD inline void fwd_block(const Sys& sy, const BlockDesc& bd, const ChainCon
   const double* v = vb + sy.V0 + (size_t)bd.step0 * V;
   const double* n = q + sy.U + sy.NV;
   for (int i = 0; i < RM; ++i) cp[i] = 0.0;
-  int s = 0;
-  for (int j = 0; j < bd.nobs; ++j) {
-    for (int i = 0; i < sy.S; ++i, ++s) {
-      if (traj)
-        for (int a = 0; a < X; ++a) traj[(size_t)s * X + a] = x[a];
-      M::step(cc.k, x, v + (size_t)s * V, xn);
-      for (int a = 0; a < X; ++a) x[a] = xn[a];
+  const int L = bd.nsteps;
+  // loads run up to PF steps past the block's end (never consumed): every q-like buffer is allocated with
+  // CHMC_Q_PAD doubles of slack so that the scan needs no per-element bounds branches
+  double cur[PF * V], nxt[PF * V];
+  CHMC_UNROLL
+  for (int i = 0; i < PF * V; ++i) cur[i] = v[i];
+  int cnt = sy.S, j = 0;
+  for (int s0 = 0; s0 < L; s0 += PF) {
+    const double* vn = v + (size_t)(s0 + PF) * V;
+    CHMC_UNROLL
+    for (int i = 0; i < PF * V; ++i) nxt[i] = vn[i];
+    CHMC_UNROLL
+    for (int i = 0; i < PF; ++i) {
+      const int s = s0 + i;
+      if (s < L) {
+        if (traj)
+          for (int a = 0; a < X; ++a) traj[(size_t)s * X + a] = x[a];
+        M::step(cc.k, x, cur + i * V, xn);
+        for (int a = 0; a < X; ++a) x[a] = xn[a];
+        if (--cnt == 0) {  // s + 1 is the time of local observation j
+          if (j < bd.ny) {
+            double yv = M::obs(x);
+            if (sy.noisy) yv += sy.sigma * n[bd.obs0 + j];
+            cp[j] = yv - sy.y[bd.obs0 + j];
+          }
+          ++j;
+          cnt = sy.S;
+        }
+      }
     }
-    if (j < bd.ny) {
-      double yv = M::obs(x);
-      if (sy.noisy) yv += sy.sigma * n[bd.obs0 + j];
-      cp[j] = yv - sy.y[bd.obs0 + j];
-    }
+    CHMC_UNROLL
+    for (int i = 0; i < PF * V; ++i) cur[i] = nxt[i];
   }
   if (traj)
-    for (int a = 0; a < X; ++a) traj[(size_t)s * X + a] = x[a];
+    for (int a = 0; a < X; ++a) traj[(size_t)L * X + a] = x[a];
   if (!bd.last)
     for (int a = 0; a < X; ++a) cp[bd.ny + a] = x[a] - xobs[(bd.obs0 + bd.nobs - 1) * X + a];
 }
@@ -462,10 +501,12 @@ struct KFwd {
     CHMC_CB_DECODE
     if (use_nw ? !w.nw[c] : !w.ok[c]) return;
     const int s = sl.cur[c] ^ which;
-    const double* q = (qsel ? w.qb : sl.q[s]) + (size_t)c * sy.Q;
+    const double* q = (qsel ? w.qb : pick(sl.q, s)) + (size_t)c * sy.Q;
     ChainConsts<M> cc;
     cc.init(q, sy.dl);
-    double* traj = store_traj ? sl.traj[s] + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * M::X : nullptr;
+    // store_traj: 0 none, 1 into the slot, 2 into the Newton-iterate work trajectory
+    double* traj = store_traj ? (store_traj == 2 ? w.trajw : pick(sl.traj, s)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * M::X
+                              : nullptr;
     double cp[RM];
     fwd_block<M, RM>(sy, bd, cc, q, sy.xobs + (size_t)c * sy.T * M::X, traj, cp);
     double* out = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
@@ -473,28 +514,44 @@ struct KFwd {
   }
 };
 
-// generate_x_obs_seq (:384-397): one work item per chain
+// generate_x_obs_seq (:384-397): one work item per chain; same software-prefetched scan as fwd_block
 template <class M>
 struct KXobs {
   Sys sy;
   Slots sl;
   double* xobs_out;
   CHMC_HD void operator()(int c) const {
-    constexpr int X = M::X, V = M::V;
-    const double* q = sl.q[sl.cur[c]] + (size_t)c * sy.Q;
+    constexpr int X = M::X, V = M::V, PF = 8;
+    const double* q = pick(sl.q, sl.cur[c]) + (size_t)c * sy.Q;
     ChainConsts<M> cc;
     cc.init(q, sy.dl);
     double x[X], xn[X];
     M::gx0(cc.z, q + sy.U, x);
     const double* v = q + sy.U + sy.V0;
     double* out = xobs_out + (size_t)c * sy.T * X;
-    for (int t = 0; t < sy.T; ++t) {
-      for (int i = 0; i < sy.S; ++i) {
-        M::step(cc.k, x, v, xn);
-        for (int a = 0; a < X; ++a) x[a] = xn[a];
-        v += V;
+    const int L = sy.T * sy.S;
+    double cur[PF * V], nxt[PF * V];
+    CHMC_UNROLL
+    for (int i = 0; i < PF * V; ++i) cur[i] = v[i];
+    int cnt = sy.S, t = 0;
+    for (int s0 = 0; s0 < L; s0 += PF) {
+      const double* vn = v + (size_t)(s0 + PF) * V;
+      CHMC_UNROLL
+      for (int i = 0; i < PF * V; ++i) nxt[i] = vn[i];
+      CHMC_UNROLL
+      for (int i = 0; i < PF; ++i) {
+        if (s0 + i < L) {
+          M::step(cc.k, x, cur + i * V, xn);
+          for (int a = 0; a < X; ++a) x[a] = xn[a];
+          if (--cnt == 0) {
+            for (int a = 0; a < X; ++a) out[t * X + a] = x[a];
+            ++t;
+            cnt = sy.S;
+          }
+        }
       }
-      for (int a = 0; a < X; ++a) out[t * X + a] = x[a];
+      CHMC_UNROLL
+      for (int i = 0; i < PF * V; ++i) cur[i] = nxt[i];
     }
   }
 };
@@ -512,27 +569,27 @@ struct KStateBlk {
     if (!w.ok[c]) return;
     constexpr int U = M::Z;
     const int s = sl.cur[c] ^ which;
-    const double* q = sl.q[s] + (size_t)c * sy.Q;
+    const double* q = pick(sl.q, s) + (size_t)c * sy.Q;
     ChainConsts<M> cc;
     cc.init(q, sy.dl);
-    double* traj = sl.traj[s] + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * M::X;
+    double* traj = pick(sl.traj, s) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * M::X;
     double cp[RM];
     fwd_block<M, RM>(sy, bd, cc, q, sy.xobs + (size_t)c * sy.T * M::X, traj, cp);
     double* cout_ = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
     for (int i = 0; i < RM; ++i) cout_[i] = cp[i];
     double D[RM * RM], Ju[RM * U];
-    rev_block<M, RM, 0>(sy, bd, cc, q, q, traj, sl.Jv[s] + (size_t)c * RM * sy.NV, nullptr, Ju, D);
+    rev_block<M, RM, 0>(sy, bd, cc, q, q, traj, pick(sl.Jv, s) + (size_t)c * RM * sy.NV, nullptr, Ju, D);
     const size_t cb = (size_t)c * sy.Kmax + b;
     double ld = chol_lower<RM>(D);
-    double* fd = sl.facD[s] + cb * RM * RM;
+    double* fd = pick(sl.facD, s) + cb * RM * RM;
     for (int i = 0; i < RM * RM; ++i) fd[i] = D[i];
-    sl.ldb[s][cb] = ld;
-    double* ju = sl.JuP[s] + cb * RM * U;
+    pick(sl.ldb, s)[cb] = ld;
+    double* ju = pick(sl.JuP, s) + cb * RM * U;
     for (int i = 0; i < RM * U; ++i) ju[i] = Ju[i];
     double E[RM * U];
     for (int i = 0; i < RM * U; ++i) E[i] = Ju[i];
     cho_solve<RM, U>(D, E);
-    double* eo = sl.E[s] + cb * RM * U;
+    double* eo = pick(sl.E, s) + cb * RM * U;
     for (int i = 0; i < RM * U; ++i) eo[i] = E[i];
     double* Cb = w.Cb + cb * U * U;
     for (int a = 0; a < U; ++a)
@@ -563,7 +620,7 @@ struct KStateChain {
     for (int b = 0; b < sy.K; ++b) {
       const double* Cb = w.Cb + ((size_t)c * sy.Kmax + b) * U * U;
       for (int i = 0; i < U * U; ++i) Cm[i] += Cb[i];
-      ld += sl.ldb[s][(size_t)c * sy.Kmax + b];
+      ld += pick(sl.ldb, s)[(size_t)c * sy.Kmax + b];
     }
     ld += chol_lower<U>(Cm);
     double Ci[U * U];
@@ -571,10 +628,10 @@ struct KStateChain {
     for (int i = 0; i < U; ++i) Ci[i * U + i] = 1.0;
     cho_solve<U, U>(Cm, Ci);
     for (int i = 0; i < U * U; ++i) {
-      sl.facC[s][(size_t)c * U * U + i] = Cm[i];
-      sl.Cinv[s][(size_t)c * U * U + i] = Ci[i];
+      pick(sl.facC, s)[(size_t)c * U * U + i] = Cm[i];
+      pick(sl.Cinv, s)[(size_t)c * U * U + i] = Ci[i];
     }
-    sl.logdet[s][c] = ld;
+    pick(sl.logdet, s)[c] = ld;
   }
 };
 
@@ -594,12 +651,12 @@ struct KGldBlk {
     const int s = sl.cur[c] ^ which;
     const int S = sy.S, L = bd.nsteps, NV = sy.NV;
     const size_t cb = (size_t)c * sy.Kmax + b;
-    const double* q = sl.q[s] + (size_t)c * sy.Q;
-    const double* traj = sl.traj[s] + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
-    const double* Jv = sl.Jv[s] + (size_t)c * RM * NV;
+    const double* q = pick(sl.q, s) + (size_t)c * sy.Q;
+    const double* traj = pick(sl.traj, s) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+    const double* Jv = pick(sl.Jv, s) + (size_t)c * RM * NV;
     const double* v = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
     const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
-    double* gv = sl.grad[s] + (size_t)c * sy.Q + sy.U;
+    double* gv = pick(sl.grad, s) + (size_t)c * sy.Q + sy.U;
     double* Xd = w.Xd + ((size_t)c * sy.T * S + bd.step0) * RM * X;
     ChainConsts<M> cc;
     cc.init(q, sy.dl);
@@ -609,10 +666,10 @@ struct KGldBlk {
     // Wu = D^-1 Ju C^-1 (rows of G^-1 dc/du);  Mb = (G^-1)_bb = D^-1 - E C^-1 E^T
     double Wu[RM * U], Mb[RM * RM], zd[RM * Z];
     {
-      const double* E = sl.E[s] + cb * RM * U;
-      const double* Ci = sl.Cinv[s] + (size_t)c * U * U;
+      const double* E = pick(sl.E, s) + cb * RM * U;
+      const double* Ci = pick(sl.Cinv, s) + (size_t)c * U * U;
       double Dl[RM * RM];
-      const double* fd = sl.facD[s] + cb * RM * RM;
+      const double* fd = pick(sl.facD, s) + cb * RM * RM;
       for (int i = 0; i < RM * RM; ++i) Dl[i] = fd[i];
       for (int i = 0; i < RM; ++i)
         for (int d = 0; d < U; ++d) {
@@ -838,6 +895,57 @@ struct KGldBlk {
   }
 };
 
+// Per-block quantities of the grad-log-det evaluation that do not depend on the time step (wave kernels read them):
+// Wu = D^-1 Ju C^-1 (rows of G^-1 dc/du), Mb = (G^-1)_bb = D^-1 - E C^-1 E^T, zd_i = generate_z'(u) Wu_i.
+template <class M, int RM>
+struct KGldPrep {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which;
+  CHMC_HD void operator()(int tid) const {
+    CHMC_CB_DECODE
+    if (!w.ok[c]) return;
+    constexpr int Z = M::Z, U = M::Z;
+    const int s = sl.cur[c] ^ which;
+    const size_t cb = (size_t)c * sy.Kmax + b;
+    const double* q = pick(sl.q, s) + (size_t)c * sy.Q;
+    double Gz[Z * Z], Wu[RM * U], Mb[RM * RM], Dl[RM * RM];
+    M::gz_jac(q, Gz);
+    const double* E = pick(sl.E, s) + cb * RM * U;
+    const double* Ci = pick(sl.Cinv, s) + (size_t)c * U * U;
+    for (int i = 0; i < RM * RM; ++i) Dl[i] = pick(sl.facD, s)[cb * RM * RM + i];
+    for (int i = 0; i < RM; ++i)
+      for (int d = 0; d < U; ++d) {
+        double t = 0.0;
+        for (int a = 0; a < U; ++a) t += E[i * U + a] * Ci[a * U + d];
+        Wu[i * U + d] = t;
+      }
+    for (int i = 0; i < RM * RM; ++i) Mb[i] = 0.0;
+    for (int i = 0; i < RM; ++i) Mb[i * RM + i] = 1.0;
+    cho_solve<RM, RM>(Dl, Mb);
+    for (int i = 0; i < RM; ++i)
+      for (int j = 0; j < RM; ++j) {
+        double t = 0.0;
+        for (int a = 0; a < U; ++a) t += Wu[i * U + a] * E[j * U + a];
+        Mb[i * RM + j] -= t;
+      }
+    for (int i = 0; i < RM; ++i) {
+      if (i >= bd.nrows)
+        for (int j = 0; j < RM; ++j) Mb[i * RM + j] = 0.0, Mb[j * RM + i] = 0.0;
+    }
+    for (int i = 0; i < RM * RM; ++i) w.gMb[cb * RM * RM + i] = Mb[i];
+    for (int i = 0; i < RM; ++i) {
+      for (int d = 0; d < U; ++d) w.gWu[(cb * RM + i) * U + d] = Wu[i * U + d];
+      for (int mz = 0; mz < Z; ++mz) {
+        double t = 0.0;
+        for (int d = 0; d < U; ++d) t += Gz[mz * Z + d] * Wu[i * U + d];
+        w.gzd[(cb * RM + i) * Z + mz] = t;
+      }
+    }
+  }
+};
+
 template <class M>
 struct KGldChain {
   Sys sy;
@@ -848,7 +956,7 @@ struct KGldChain {
     if (!w.ok[c]) return;
     constexpr int U = M::Z;
     const int s = sl.cur[c] ^ which;
-    double* g = sl.grad[s] + (size_t)c * sy.Q;
+    double* g = pick(sl.grad, s) + (size_t)c * sy.Q;
     for (int d = 0; d < U; ++d) {
       double t = 0.0;
       for (int b = 0; b < sy.K; ++b) t += w.gup[((size_t)c * sy.Kmax + b) * U + d];
@@ -873,7 +981,7 @@ struct KNewtonBlk {
     if (!w.nw[c]) return;
     constexpr int U = M::Z;
     const int sp = sl.cur[c] ^ prev;
-    const double* q = (qsel ? w.qb : sl.q[sp ^ 1]) + (size_t)c * sy.Q;
+    const double* q = (qsel ? w.qb : pick(sl.q, sp ^ 1)) + (size_t)c * sy.Q;
     ChainConsts<M> cc;
     cc.init(q, sy.dl);
     double* traj = w.trajw + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * M::X;
@@ -883,7 +991,7 @@ struct KNewtonBlk {
     double* cout_ = w.cpad + cb * RM;
     for (int i = 0; i < RM; ++i) cout_[i] = cp[i];
     double D[RM * RM], JuL[RM * U];
-    rev_block<M, RM, 1>(sy, bd, cc, q, q, traj, nullptr, sl.Jv[sp] + (size_t)c * RM * sy.NV, JuL, D);
+    rev_block<M, RM, 1>(sy, bd, cc, q, q, traj, nullptr, pick(sl.Jv, sp) + (size_t)c * RM * sy.NV, JuL, D);
     int piv[RM];
     lu_factor<RM>(D, piv);
     lu_solve<RM, 1>(D, piv, cp);
@@ -892,7 +1000,7 @@ struct KNewtonBlk {
     for (int i = 0; i < RM; ++i) to[i] = cp[i];
     double* eo = w.Ew + cb * RM * U;
     for (int i = 0; i < RM * U; ++i) eo[i] = JuL[i];
-    const double* jur = sl.JuP[sp] + cb * RM * U;
+    const double* jur = pick(sl.JuP, sp) + cb * RM * U;
     double* Cb = w.Cb + cb * U * U;
     double* sb = w.sb + cb * U;
     for (int a = 0; a < U; ++a) {
@@ -905,6 +1013,74 @@ struct KNewtonBlk {
         Cb[a * U + d] = t;
       }
     }
+  }
+};
+
+// Factor kernels: the small dense algebra of one block, reading the Gram block D and the dc/du rows produced
+// by the wave-level reverse sweep (chmc_wave.h).  One work item per (chain, block) so that all 64 lanes of a
+// wave factor 64 different blocks.
+template <class M, int RM>
+struct KNewtonFactor {  // LU of D = Jv(q) Jv(q_prev)^T + diag, D^-1 c, D^-1 dc/du, C_b, s_b  (:745-762, :957-969)
+  Sys sy;
+  Slots sl;
+  Work w;
+  int prev;
+  CHMC_HD void operator()(int tid) const {
+    CHMC_CB_DECODE
+    if (!w.nw[c]) return;
+    (void)bd;
+    constexpr int U = M::Z;
+    const int sp = sl.cur[c] ^ prev;
+    const size_t cb = (size_t)c * sy.Kmax + b;
+    double D[RM * RM], JuL[RM * U], cp[RM];
+    for (int i = 0; i < RM * RM; ++i) D[i] = w.Dw[cb * RM * RM + i];
+    for (int i = 0; i < RM * U; ++i) JuL[i] = w.JuL[cb * RM * U + i];
+    for (int i = 0; i < RM; ++i) cp[i] = w.cpad[cb * RM + i];
+    int piv[RM];
+    lu_factor<RM>(D, piv);
+    lu_solve<RM, 1>(D, piv, cp);
+    lu_solve<RM, U>(D, piv, JuL);
+    for (int i = 0; i < RM; ++i) w.tpad[cb * RM + i] = cp[i];
+    for (int i = 0; i < RM * U; ++i) w.Ew[cb * RM * U + i] = JuL[i];
+    const double* jur = pick(sl.JuP, sp) + cb * RM * U;
+    for (int a = 0; a < U; ++a) {
+      double t2 = 0.0;
+      for (int i = 0; i < RM; ++i) t2 += jur[i * U + a] * cp[i];
+      w.sb[cb * U + a] = t2;
+      for (int d = 0; d < U; ++d) {
+        double t = 0.0;
+        for (int i = 0; i < RM; ++i) t += jur[i * U + a] * JuL[i * U + d];
+        w.Cb[(cb * U + a) * U + d] = t;
+      }
+    }
+  }
+};
+template <class M, int RM>
+struct KStateFactor {  // Cholesky of D = Jv Jv^T + diag, D^-1 dc/du, C_b, log det share  (:668-686)
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which;
+  CHMC_HD void operator()(int tid) const {
+    CHMC_CB_DECODE
+    if (!w.ok[c]) return;
+    (void)bd;
+    constexpr int U = M::Z;
+    const int s = sl.cur[c] ^ which;
+    const size_t cb = (size_t)c * sy.Kmax + b;
+    double D[RM * RM], Ju[RM * U], E[RM * U];
+    for (int i = 0; i < RM * RM; ++i) D[i] = w.Dw[cb * RM * RM + i];
+    for (int i = 0; i < RM * U; ++i) Ju[i] = E[i] = pick(sl.JuP, s)[cb * RM * U + i];
+    pick(sl.ldb, s)[cb] = chol_lower<RM>(D);
+    for (int i = 0; i < RM * RM; ++i) pick(sl.facD, s)[cb * RM * RM + i] = D[i];
+    cho_solve<RM, U>(D, E);
+    for (int i = 0; i < RM * U; ++i) pick(sl.E, s)[cb * RM * U + i] = E[i];
+    for (int a = 0; a < U; ++a)
+      for (int d = 0; d < U; ++d) {
+        double t = 0.0;
+        for (int i = 0; i < RM; ++i) t += Ju[i * U + a] * E[i * U + d];
+        w.Cb[(cb * U + a) * U + d] = t;
+      }
   }
 };
 
@@ -923,12 +1099,12 @@ struct KSymBlk {
     const int s = sl.cur[c] ^ which;
     const size_t cb = (size_t)c * sy.Kmax + b;
     double Dl[RM * RM], t[RM];
-    const double* fd = sl.facD[s] + cb * RM * RM;
+    const double* fd = pick(sl.facD, s) + cb * RM * RM;
     for (int i = 0; i < RM * RM; ++i) Dl[i] = fd[i];
     for (int i = 0; i < RM; ++i) t[i] = w.cpad[cb * RM + i];
     cho_solve<RM, 1>(Dl, t);
     for (int i = 0; i < RM; ++i) w.tpad[cb * RM + i] = t[i];
-    const double* ju = sl.JuP[s] + cb * RM * U;
+    const double* ju = pick(sl.JuP, s) + cb * RM * U;
     for (int a = 0; a < U; ++a) {
       double acc = 0.0;
       for (int i = 0; i < RM; ++i) acc += ju[i * U + a] * t[i];
@@ -960,7 +1136,7 @@ struct KSolveChain {
       for (int a = 0; a < U; ++a) sacc[a] += w.sb[((size_t)c * sy.Kmax + b) * U + a];
     if (SYM) {
       double Lc[U * U];
-      for (int i = 0; i < U * U; ++i) Lc[i] = sl.facC[s][(size_t)c * U * U + i];
+      for (int i = 0; i < U * U; ++i) Lc[i] = pick(sl.facC, s)[(size_t)c * U * U + i];
       cho_solve<U, 1>(Lc, sacc);
     } else {
       double Cm[U * U];
@@ -977,8 +1153,8 @@ struct KSolveChain {
     unsigned long long eb = 0ULL;
     for (int b = 0; b < sy.K; ++b) {
       const size_t cb = (size_t)c * sy.Kmax + b;
-      const double* E = (SYM ? sl.E[s] : w.Ew) + cb * RM * U;
-      const double* ju = sl.JuP[s] + cb * RM * U;
+      const double* E = (SYM ? pick(sl.E, s) : w.Ew) + cb * RM * U;
+      const double* ju = pick(sl.JuP, s) + cb * RM * U;
       for (int i = 0; i < RM; ++i) {
         double l = w.tpad[cb * RM + i];
         for (int a = 0; a < U; ++a) l -= E[i * U + a] * sacc[a];
@@ -991,7 +1167,7 @@ struct KSolveChain {
       }
     }
     if (TGT == 0) {
-      double* q = (qsel ? w.qb : sl.q[s ^ 1]) + (size_t)c * sy.Q;
+      double* q = (qsel ? w.qb : pick(sl.q, s ^ 1)) + (size_t)c * sy.Q;
       double* mu = w.mu + (size_t)c * sy.Q;
       unsigned long long nb = 0ULL;
       for (int a = 0; a < U; ++a) {
@@ -1003,7 +1179,7 @@ struct KSolveChain {
       w.err[c] = bitsd(eb);
       w.ndq[c] = nb;
     } else if (TGT == 1) {
-      double* p = (psel == 0 ? sl.p[s] : psel == 1 ? w.pb : sl.p[s ^ 1]) + (size_t)c * sy.Q;
+      double* p = (psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
       for (int a = 0; a < U; ++a) p[a] -= du[a];
     }
   }
@@ -1028,7 +1204,7 @@ struct KUpdate {
       int g = col < sy.V0 ? 0 : (col - sy.V0) / sy.V / sy.S;
       const int b = sy.obs2blk[g];
       const double* lam = w.lampad + ((size_t)c * sy.Kmax + b) * RM;
-      const double* Jv = sl.Jv[s] + (size_t)c * RM * sy.NV + col;
+      const double* Jv = pick(sl.Jv, s) + (size_t)c * RM * sy.NV + col;
       d = 0.0;
       CHMC_UNROLL
       for (int i = 0; i < RM; ++i) d += Jv[(size_t)i * sy.NV] * lam[i];
@@ -1040,12 +1216,12 @@ struct KUpdate {
     }
     const size_t qi = (size_t)c * sy.Q + sy.U + col;
     if (TGT == 0) {
-      double* q = qsel ? w.qb : sl.q[s ^ 1];
+      double* q = qsel ? w.qb : pick(sl.q, s ^ 1);
       q[qi] -= d;
       w.mu[qi] += d;
       return absbits(d);
     } else if (TGT == 1) {
-      double* p = psel == 0 ? sl.p[s] : psel == 1 ? w.pb : sl.p[s ^ 1];
+      double* p = psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : pick(sl.p, s ^ 1);
       p[qi] -= d;
     } else {
       w.pb[qi] = d;
@@ -1105,13 +1281,13 @@ struct KJw {
     if (!w.ok[c]) return;
     const BlockDesc bd = sy.blk[b];
     const int s = sl.cur[c] ^ which;
-    const double* vct = (vsel == 0 ? sl.p[s] : vsel == 1 ? w.pb : vsel == 2 ? w.vin : sl.p[s ^ 1]) + (size_t)c * sy.Q;
+    const double* vct = (vsel == 0 ? pick(sl.p, s) : vsel == 1 ? w.pb : vsel == 2 ? w.vin : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
     const size_t cb = (size_t)c * sy.Kmax + b;
     double acc = 0.0;
     if (i < bd.nrows) {
-      const double* ju = sl.JuP[s] + (cb * RM + i) * sy.U;
+      const double* ju = pick(sl.JuP, s) + (cb * RM + i) * sy.U;
       for (int a = 0; a < sy.U; ++a) acc += ju[a] * vct[a];
-      const double* Jv = sl.Jv[s] + ((size_t)c * RM + i) * sy.NV + bd.col0;
+      const double* Jv = pick(sl.Jv, s) + ((size_t)c * RM + i) * sy.NV + bd.col0;
       const double* wv = vct + sy.U + bd.col0;
       double a2 = 0.0;
       for (int k = 0; k < bd.ncols; ++k) a2 += Jv[k] * wv[k];
@@ -1136,9 +1312,9 @@ struct KKick {
     if (!w.ok[c]) return;
     const int s = sl.cur[c] ^ which;
     const double h = hfrac * w.dt[c];
-    const double g = sl.grad[s][tid] + (sy.gaussian ? 0.0 : sl.q[s][tid]);
-    const double pin = sl.p[s][tid];
-    (out_other ? sl.p[s ^ 1] : sl.p[s])[tid] = pin - h * g;
+    const double g = pick(sl.grad, s)[tid] + (sy.gaussian ? 0.0 : pick(sl.q, s)[tid]);
+    const double pin = pick(sl.p, s)[tid];
+    (out_other ? pick(sl.p, s ^ 1) : pick(sl.p, s))[tid] = pin - h * g;
   }
 };
 // h2_flow (:1222-1231) from slot `from` into (q_out, p_out): dst 0 = other slot, dst 1 = work (qb, pb)
@@ -1153,11 +1329,11 @@ struct KFlow {
     if (!w.ok[c]) return;
     const int s = sl.cur[c] ^ from;
     const double dt = sign * w.dt[c];
-    const double q0 = sl.q[s][tid];
-    const double p0 = from_p_other ? sl.p[s ^ 1][tid] : sl.p[s][tid];
+    const double q0 = pick(sl.q, s)[tid];
+    const double p0 = from_p_other ? pick(sl.p, s ^ 1)[tid] : pick(sl.p, s)[tid];
     double qn, pn;
-    if (sy.gaussian) {
-      const double sn = sin(dt), cs = cos(dt);
+    if (sy.gaussian) {  // sin / cos of dt[c] are evaluated once per chain (KBegin), not per component
+      const double sn = sign * w.sdt[c], cs = w.cdt[c];
       qn = q0 * cs + sn * p0;
       pn = p0 * cs - sn * q0;
     } else {
@@ -1165,8 +1341,8 @@ struct KFlow {
       pn = p0;
     }
     if (dst == 0) {
-      sl.q[s ^ 1][tid] = qn;
-      sl.p[s ^ 1][tid] = pn;
+      pick(sl.q, s ^ 1)[tid] = qn;
+      pick(sl.p, s ^ 1)[tid] = pn;
     } else {
       w.qb[tid] = qn;
       w.pb[tid] = pn;
@@ -1183,9 +1359,8 @@ struct KMomFix {
     const int c = tid / sy.Q;
     if (!w.ok[c]) return;
     const int s = sl.cur[c] ^ which;
-    const double dt = w.dt[c];
-    const double sc = sy.gaussian ? cos(dt) / sin(dt) : 1.0 / dt;
-    sl.p[s][tid] -= sc * w.mu[tid];
+    const double sc = sy.gaussian ? w.cdt[c] / w.sdt[c] : 1.0 / w.dt[c];
+    pick(sl.p, s)[tid] -= sc * w.mu[tid];
   }
 };
 // reverse check distance max |q_back - q_start| (mici maximum_norm); column-max kernel over all Q components
@@ -1223,7 +1398,11 @@ struct KBegin {
   CHMC_HD void operator()(int c) const {
     w.ok[c] = active ? (active[c] != 0) : 1;
     w.status[c] = w.ok[c] ? 0 : -1;
-    if (dt) w.dt[c] = dt[c];
+    if (dt) {
+      w.dt[c] = dt[c];
+      w.sdt[c] = sin(dt[c]);
+      w.cdt[c] = cos(dt[c]);
+    }
     w.rev[c] = 0ULL;
   }
 };
@@ -1239,8 +1418,8 @@ struct KNormPart {
     const int chunk = (sy.Q + npart - 1) / npart;
     const int lo = j * chunk, hi = lo + chunk < sy.Q ? lo + chunk : sy.Q;
     double qq = 0.0, pp = 0.0;
-    const double* q = sl.q[s] + (size_t)c * sy.Q;
-    const double* p = sl.p[s] + (size_t)c * sy.Q;
+    const double* q = pick(sl.q, s) + (size_t)c * sy.Q;
+    const double* p = pick(sl.p, s) + (size_t)c * sy.Q;
     for (int i = lo; i < hi; ++i) qq += q[i] * q[i], pp += p[i] * p[i];
     w.part[((size_t)c * npart + j) * 2] = qq;
     w.part[((size_t)c * npart + j) * 2 + 1] = pp;

@@ -1,0 +1,842 @@
+// Wave-level kernels for gfx950: one 64-lane wavefront per (chain, block).
+//
+// The adjoint recurrence behind the constraint Jacobian (jacob_constr_blocks, sde/mici_extensions.py:521-624)
+//     Lam^(s) = Lam^(s+1) A_s,   dc/dv_s = Lam^(s+1) B_s,   dc/dz += Lam^(s+1) Zf_s
+// is linear in Lam, so a tile of 64 consecutive time steps is processed by the 64 lanes at once:
+//   * lane l loads x_s, v_s of step s = tile_base + l  (unit-stride, 16 B per lane: fully coalesced),
+//   * evaluates its own A_s, B_s, Zf_s,
+//   * a 6-level suffix scan over the lanes (shuffles) forms A_hi ... A_{s+1}, which maps the carried adjoint
+//     rows at the tile end to this lane's step,
+//   * every lane forms its RM x V Jacobian entries, stores them (MODE 0) and accumulates its share of the Gram
+//     block D = Jv Jv'^T in registers (against the stored rows of the previous point in MODE 1),
+//   * lane 0's inclusive product carries the adjoint rows to the next (earlier) tile.
+// Gram / dc/dz partial sums are combined over the wave by a butterfly of shuffles at the end.
+// Compared with one lane per block this turns 7 x 16-byte scattered loads per step per lane into 1 KB
+// contiguous wave loads and gives 64x more lanes of parallelism.
+#pragma once
+#include "chmc_core.h"
+
+namespace chmc {
+
+__device__ inline double bcast0(double x) {  // value of lane 0, as a wave-uniform value
+  union { double d; int i[2]; } u;
+  u.d = x;
+  u.i[0] = __builtin_amdgcn_readfirstlane(u.i[0]);
+  u.i[1] = __builtin_amdgcn_readfirstlane(u.i[1]);
+  return u.d;
+}
+
+template <int X>
+__device__ inline void matmul_xx(const double* a, const double* b, double* c) {  // c = a b (X x X)
+#pragma unroll
+  for (int i = 0; i < X; ++i)
+#pragma unroll
+    for (int j = 0; j < X; ++j) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < X; ++k) t += a[i * X + k] * b[k * X + j];
+      c[i * X + j] = t;
+    }
+}
+
+// MODE 0: state evaluation -- store dc/dv rows, symmetric Gram, dc/du rows into the slot.
+// MODE 1: Newton iteration -- Gram of the iterate's rows against the stored rows of slot `which`.
+template <class M, int RM, int MODE>
+__global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int which, int qsel) {
+  constexpr int X = M::X, V = M::V, Z = M::Z, U = M::Z, V0 = M::V0;
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wid >= sy.B * sy.K) return;
+  const int c = wid / sy.K, b = wid - c * sy.K;
+  if (MODE == 1 ? !w.nw[c] : !w.ok[c]) return;
+  const BlockDesc bd = sy.blk[b];
+  const int sl_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int S = sy.S, NV = sy.NV;
+  const double* q = (MODE == 1 ? (qsel ? w.qb : pick(sl.q, sl_ ^ 1)) : pick(sl.q, sl_)) + (size_t)c * sy.Q;
+  const double* traj = (MODE == 1 ? w.trajw : pick(sl.traj, sl_)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* Jr = pick(sl.Jv, sl_) + (size_t)c * RM * NV;  // MODE 1: read; MODE 0: written through Jo
+  double* Jo = pick(sl.Jv, sl_) + (size_t)c * RM * NV;
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
+
+  double Lam[RM * X], Dacc[RM * RM], zacc[RM * Z];
+#pragma unroll
+  for (int i = 0; i < RM * X; ++i) Lam[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < RM * RM; ++i) Dacc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < RM * Z; ++i) zacc[i] = 0.0;
+
+  // The tiles are walked backwards in time; the raw inputs of the NEXT tile (state, noise increment, stored rows)
+  // are requested before the current tile is processed, so their HBM latency overlaps the scan arithmetic
+  // (one wavefront per SIMD is resident at this register footprint, there is no other wave to hide it).
+  const int ntile = (S + 63) >> 6;
+  const int ntot = bd.nobs * ntile;
+  double cx[X], cv[V], cjp[RM * V];
+  bool cvalid;
+  int cs;
+  auto fetch = [&](int tt, double* x, double* vv, double* jp, bool& valid, int& sidx) {
+    const int jj = tt / ntile, t = tt - jj * ntile;
+    const int off = (t << 6) + lane;
+    valid = off < S;
+    sidx = jj * S + off;
+    if (valid) {
+#pragma unroll
+      for (int a = 0; a < X; ++a) x[a] = traj[(size_t)sidx * X + a];
+#pragma unroll
+      for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)sidx * V + a];
+      if (MODE == 1) {
+        const size_t col = colb + (size_t)sidx * V;
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int d = 0; d < V; ++d) jp[i * V + d] = Jr[(size_t)i * NV + col + d];
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < X; ++a) x[a] = 0.0;
+#pragma unroll
+      for (int a = 0; a < V; ++a) vv[a] = 0.0;
+      if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < RM * V; ++i) jp[i] = 0.0;
+      }
+    }
+  };
+  fetch(ntot - 1, cx, cv, cjp, cvalid, cs);
+  for (int tt = ntot - 1; tt >= 0; --tt) {
+    const int j = tt / ntile, t = tt - j * ntile;
+    double nx[X], nv[V], njp[RM * V];
+    bool nvalid = false;
+    int ns = 0;
+    if (tt > 0) fetch(tt - 1, nx, nv, njp, nvalid, ns);
+    if (t == ntile - 1) {
+      // rows that start at the end of observation interval j
+      if (j < bd.ny) {
+        double g[X];
+        M::obs_grad(traj + (size_t)(j + 1) * S * X, g);
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+          if (i == j)
+#pragma unroll
+            for (int a = 0; a < X; ++a) Lam[i * X + a] = g[a];
+      }
+      if (j == bd.nobs - 1 && !bd.last) {
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int a = 0; a < X; ++a)
+            if (i == bd.ny + a) Lam[i * X + a] = 1.0;
+      }
+    }
+    {
+      const bool valid = cvalid;
+      const int s = cs;
+      double A[X * X], Bm[X * V], Zf[X * Z];
+      if (valid) {
+        M::jac(cc.k, cx, cv, A, Bm, Zf);
+      } else {
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+      }
+      // inclusive suffix scan: Inc_l = A_{hi} ... A_{l}  (later steps on the left)
+      double Inc[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        double Y[X * X], P[X * X];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o, 64);
+        matmul_xx<X>(Y, Inc, P);
+        if (lane + o < 64) {
+#pragma unroll
+          for (int i = 0; i < X * X; ++i) Inc[i] = P[i];
+        }
+      }
+      double E[X * X];  // exclusive: product over the later lanes only
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) {
+        const double y = __shfl_down(Inc[i], 1, 64);
+        E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
+      }
+      double Ls[RM * X], jr[RM * V];
+#pragma unroll
+      for (int i = 0; i < RM; ++i) {
+#pragma unroll
+        for (int d = 0; d < X; ++d) {
+          double tt2 = 0.0;
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt2 += Lam[i * X + a] * E[a * X + d];
+          Ls[i * X + d] = tt2;
+        }
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          double tt2 = 0.0;
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * Bm[a * V + d];
+          jr[i * V + d] = tt2;
+        }
+#pragma unroll
+        for (int mz = 0; mz < Z; ++mz) {
+          double tt2 = zacc[i * Z + mz];
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * Zf[a * Z + mz];
+          zacc[i * Z + mz] = tt2;
+        }
+      }
+      const size_t col = colb + (size_t)s * V;
+      if (MODE == 0) {
+        if (valid) {
+#pragma unroll
+          for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int d = 0; d < V; ++d) Jo[(size_t)i * NV + col + d] = jr[i * V + d];
+        }
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int jj = 0; jj <= i; ++jj) {
+            double tt2 = Dacc[i * RM + jj];
+#pragma unroll
+            for (int d = 0; d < V; ++d) tt2 += jr[i * V + d] * jr[jj * V + d];
+            Dacc[i * RM + jj] = tt2;
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int jj = 0; jj < RM; ++jj) {
+            double tt2 = Dacc[i * RM + jj];
+#pragma unroll
+            for (int d = 0; d < V; ++d) tt2 += jr[i * V + d] * cjp[jj * V + d];
+            Dacc[i * RM + jj] = tt2;
+          }
+      }
+      // carry the adjoint rows to the start of this tile: Lam <- Lam Inc_0
+      double I0[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) I0[i] = bcast0(Inc[i]);
+#pragma unroll
+      for (int i = 0; i < RM; ++i) {
+        double nl[X];
+#pragma unroll
+        for (int d = 0; d < X; ++d) {
+          double tt2 = 0.0;
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt2 += Lam[i * X + a] * I0[a * X + d];
+          nl[d] = tt2;
+        }
+#pragma unroll
+        for (int d = 0; d < X; ++d) Lam[i * X + d] = nl[d];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < X; ++a) cx[a] = nx[a];
+#pragma unroll
+    for (int a = 0; a < V; ++a) cv[a] = nv[a];
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < RM * V; ++i) cjp[i] = njp[i];
+    }
+    cvalid = nvalid;
+    cs = ns;
+  }
+  // x_0 = generate_x_0(z, v_0): the v_0 columns and the z-dependence of the first block (lane 0's share)
+  if (bd.first && lane == 0) {
+    double dz[X * Z], dv0[X * V0];
+    M::gx0_jac(dz, dv0);
+    double j0[RM * V0];
+    for (int i = 0; i < RM; ++i) {
+      for (int d = 0; d < V0; ++d) {
+        double tt = 0.0;
+        for (int a = 0; a < X; ++a) tt += Lam[i * X + a] * dv0[a * V0 + d];
+        j0[i * V0 + d] = tt;
+      }
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt = 0.0;
+        for (int a = 0; a < X; ++a) tt += Lam[i * X + a] * dz[a * Z + mz];
+        zacc[i * Z + mz] += tt;
+      }
+    }
+    if (MODE == 0) {
+      for (int i = 0; i < RM; ++i)
+        for (int d = 0; d < V0; ++d) Jo[(size_t)i * NV + d] = j0[i * V0 + d];
+      for (int i = 0; i < RM; ++i)
+        for (int jj = 0; jj <= i; ++jj)
+          for (int d = 0; d < V0; ++d) Dacc[i * RM + jj] += j0[i * V0 + d] * j0[jj * V0 + d];
+    } else {
+      for (int i = 0; i < RM; ++i)
+        for (int jj = 0; jj < RM; ++jj)
+          for (int d = 0; d < V0; ++d) Dacc[i * RM + jj] += j0[i * V0 + d] * Jr[(size_t)jj * NV + d];
+    }
+  }
+  // combine the per-lane partial sums over the wave
+#pragma unroll
+  for (int i = 0; i < RM * RM; ++i) {
+    if (MODE == 0 && (i % RM) > (i / RM)) continue;
+    double v = Dacc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    Dacc[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < RM * Z; ++i) {
+    double v = zacc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    zacc[i] = v;
+  }
+  if (lane == 0) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < i; ++jj) Dacc[jj * RM + i] = Dacc[i * RM + jj];
+    }
+    const double s2 = sy.sigma * sy.sigma;
+#pragma unroll
+    for (int i = 0; i < RM; ++i) {
+      if (sy.noisy && i < bd.ny) Dacc[i * RM + i] += s2;  // dc/dn dc/dn^T (:772-791)
+      if (i >= bd.nrows) Dacc[i * RM + i] = 1.0;          // identity padding
+    }
+    double* Do = w.Dw + cb * RM * RM;
+#pragma unroll
+    for (int i = 0; i < RM * RM; ++i) Do[i] = Dacc[i];
+    if (MODE == 0) {
+      double* zo = w.zbP + cb * RM * Z;
+#pragma unroll
+      for (int i = 0; i < RM * Z; ++i) zo[i] = zacc[i];
+    }
+    double G[Z * Z];
+    M::gz_jac(q, G);
+    double* ju = (MODE == 0 ? pick(sl.JuP, sl_) : w.JuL) + cb * RM * U;
+    for (int i = 0; i < RM; ++i)
+      for (int d = 0; d < Z; ++d) {
+        double tt = 0.0;
+        for (int mz = 0; mz < Z; ++mz) tt += zacc[i * Z + mz] * G[mz * Z + d];
+        ju[i * U + d] = tt;
+      }
+  }
+}
+
+// J w (lmult_by_jacob_constr :822-877): one wave per (chain, block); lanes stride over the block's columns
+// (unit-stride loads of the RM stored rows and of the vector), butterfly reduction, lane 0 adds the dc/du and
+// dc/dn terms.  Result in work.cpad.
+template <int RM>
+__global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int which, int vsel) {
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wid >= sy.B * sy.K) return;
+  const int c = wid / sy.K, b = wid - c * sy.K;
+  if (!w.ok[c]) return;
+  const BlockDesc bd = sy.blk[b];
+  const int s = sl.cur[c] ^ which;
+  const double* vct = (vsel == 0 ? pick(sl.p, s) : vsel == 1 ? w.pb : vsel == 2 ? w.vin : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const double* Jv = pick(sl.Jv, s) + (size_t)c * RM * sy.NV + bd.col0;
+  const double* wv = vct + sy.U + bd.col0;
+  double acc[RM];
+#pragma unroll
+  for (int i = 0; i < RM; ++i) acc[i] = 0.0;
+  for (int k = lane; k < bd.ncols; k += 64) {
+    const double x = wv[k];
+#pragma unroll
+    for (int i = 0; i < RM; ++i) acc[i] += Jv[(size_t)i * sy.NV + k] * x;
+  }
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+    double v = acc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    acc[i] = v;
+  }
+  if (lane < RM) {
+    const int i = lane;
+    double a = 0.0;
+#pragma unroll
+    for (int k = 0; k < RM; ++k)
+      if (k == i) a = acc[k];
+    if (i < bd.nrows) {
+      const double* ju = pick(sl.JuP, s) + (cb * RM + i) * sy.U;
+      for (int d = 0; d < sy.U; ++d) a += ju[d] * vct[d];
+      if (sy.noisy && i < bd.ny) a += sy.sigma * vct[sy.U + sy.NV + bd.obs0 + i];
+    } else {
+      a = 0.0;
+    }
+    w.cpad[cb * RM + i] = a;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Gradient of 1/2 log det Gram (value_and_grad of log_det_sqrt_gram, :812-820, :1143-1146), wave per (chain, block).
+// Same mathematics as KGldBlk (chmc_core.h); the two sweeps are wave-level scans over 64-step tiles:
+//   forward : tangents xd_i along w_i, an AFFINE prefix scan of (A_s, d_s^(1..RM)) over the lanes,
+//   backward: adjoint rows Lam (matrix suffix scan, as k_rev_wave) and the summed second-order adjoint x-bar,
+//             a joint (matrix, vector) suffix scan with the Hessian contraction as the source term.
+// Tangents are stored component-major ([RM*X][T*S] per chain) so both sweeps stream them with unit stride.
+template <class M, int RM>
+__global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, int which) {
+  constexpr int X = M::X, V = M::V, Z = M::Z, V0 = M::V0;
+  constexpr int URM = RM <= 8 ? 64 : 1;  // 16-row instantiation: keep the row loops rolled (register file)
+  __shared__ double sm[4][RM * RM + RM * Z];
+  const int lane = threadIdx.x & 63;
+  const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wid = blockIdx.x * 4 + wv_;
+  if (wid >= sy.B * sy.K) return;
+  const int c = wid / sy.K, b = wid - c * sy.K;
+  if (!w.ok[c]) return;
+  const BlockDesc bd = sy.blk[b];
+  const int s_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int S = sy.S, NV = sy.NV;
+  const size_t TS = (size_t)sy.T * S;
+  const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* Jv = pick(sl.Jv, s_) + (size_t)c * RM * NV;
+  const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
+  double* Xd = w.Xd + (size_t)c * RM * X * TS + bd.step0;
+  double* Mb = sm[wv_];
+  double* zd = sm[wv_] + RM * RM;
+  for (int i = lane; i < RM * RM; i += 64) Mb[i] = w.gMb[cb * RM * RM + i];
+  for (int i = lane; i < RM * Z; i += 64) zd[i] = w.gzd[cb * RM * Z + i];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  double xdc[RM * X];  // tangents at the start of the current tile (wave-uniform)
+#pragma unroll URM
+  for (int i = 0; i < RM * X; ++i) xdc[i] = 0.0;
+  if (bd.first) {
+    double dz[X * Z], dv0[X * V0];
+    M::gx0_jac(dz, dv0);
+    for (int i = 0; i < RM; ++i)
+      for (int a = 0; a < X; ++a) {
+        double t = 0.0;
+        for (int mz = 0; mz < Z; ++mz) t += dz[a * Z + mz] * zd[i * Z + mz];
+        for (int d = 0; d < V0; ++d) {
+          double wv = 0.0;
+          for (int jj = 0; jj < RM; ++jj) wv += Mb[i * RM + jj] * Jv[(size_t)jj * NV + d];
+          t += dv0[a * V0 + d] * wv;
+        }
+        xdc[i * X + a] = t;
+      }
+  }
+  const int ntile = (S + 63) >> 6;
+  for (int j = 0; j < bd.nobs; ++j) {
+    for (int t = 0; t < ntile; ++t) {
+      const int off = (t << 6) + lane;
+      const bool valid = off < S;
+      const int s = j * S + off;
+      double P[X * X], e[RM * X];
+      {
+        double A[X * X], Bm[X * V], Zf[X * Z], jp[RM * V];
+        if (valid) {
+          double x[X], vv[V];
+#pragma unroll
+          for (int a = 0; a < X; ++a) x[a] = traj[(size_t)s * X + a];
+#pragma unroll
+          for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
+          M::jac(cc.k, x, vv, A, Bm, Zf);
+          const size_t col = colb + (size_t)s * V;
+#pragma unroll URM
+          for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int d = 0; d < V; ++d) jp[i * V + d] = Jv[(size_t)i * NV + col + d];
+        } else {
+#pragma unroll
+          for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+          for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
+#pragma unroll
+          for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+#pragma unroll URM
+          for (int i = 0; i < RM * V; ++i) jp[i] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) P[i] = A[i];
+#pragma unroll URM
+        for (int i = 0; i < RM; ++i) {
+          double wv[V];
+#pragma unroll
+          for (int d = 0; d < V; ++d) {
+            double tt = 0.0;
+#pragma unroll URM
+            for (int jj = 0; jj < RM; ++jj) tt += Mb[i * RM + jj] * jp[jj * V + d];
+            wv[d] = tt;
+          }
+#pragma unroll
+          for (int a = 0; a < X; ++a) {
+            double tt = 0.0;
+#pragma unroll
+            for (int d = 0; d < V; ++d) tt += Bm[a * V + d] * wv[d];
+#pragma unroll
+            for (int mz = 0; mz < Z; ++mz) tt += Zf[a * Z + mz] * zd[i * Z + mz];
+            e[i * X + a] = tt;
+          }
+        }
+      }
+      // inclusive affine prefix scan: (P, e)_l maps the tangents at the tile start to those after step l
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        double Pp[X * X], ep[RM * X], Pn[X * X];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Pp[i] = __shfl_up(P[i], o, 64);
+#pragma unroll URM
+        for (int i = 0; i < RM * X; ++i) ep[i] = __shfl_up(e[i], o, 64);
+        if (lane >= o) {
+#pragma unroll URM
+          for (int i = 0; i < RM; ++i)
+#pragma unroll
+            for (int a = 0; a < X; ++a) {
+              double tt = e[i * X + a];
+#pragma unroll
+              for (int d = 0; d < X; ++d) tt += P[a * X + d] * ep[i * X + d];
+              e[i * X + a] = tt;
+            }
+          matmul_xx<X>(P, Pp, Pn);
+#pragma unroll
+          for (int i = 0; i < X * X; ++i) P[i] = Pn[i];
+        }
+      }
+      // exclusive values: tangents AT this lane's step
+      {
+        double xs[RM * X];
+#pragma unroll URM
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int a = 0; a < X; ++a) {
+            double eex = __shfl_up(e[i * X + a], 1, 64);
+            double tt = lane == 0 ? 0.0 : eex;
+            xs[i * X + a] = tt;
+          }
+        double Pex[X * X];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) {
+          const double y = __shfl_up(P[i], 1, 64);
+          Pex[i] = lane == 0 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
+        }
+#pragma unroll URM
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int a = 0; a < X; ++a) {
+            double tt = xs[i * X + a];
+#pragma unroll
+            for (int d = 0; d < X; ++d) tt += Pex[a * X + d] * xdc[i * X + d];
+            xs[i * X + a] = tt;
+          }
+        if (valid) {
+#pragma unroll URM
+          for (int i = 0; i < RM * X; ++i) Xd[(size_t)i * TS + s] = xs[i];
+        }
+      }
+      // carry to the next tile: apply lane 63's inclusive map
+      {
+        double P6[X * X], nx[RM * X];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) P6[i] = __shfl(P[i], 63, 64);
+#pragma unroll URM
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int a = 0; a < X; ++a) {
+            double tt = __shfl(e[i * X + a], 63, 64);
+#pragma unroll
+            for (int d = 0; d < X; ++d) tt += P6[a * X + d] * xdc[i * X + d];
+            nx[i * X + a] = tt;
+          }
+#pragma unroll URM
+        for (int i = 0; i < RM * X; ++i) xdc[i] = nx[i];
+      }
+    }
+    // tangent of observation row j at its terminal time (j + 1) S
+    if (j < bd.ny && lane == 0) {
+#pragma unroll URM
+      for (int i = 0; i < RM; ++i)
+        if (i == j)
+#pragma unroll
+          for (int a = 0; a < X; ++a) w.gxdt[(cb * RM + i) * X + a] = xdc[i * X + a];
+    }
+  }
+}
+
+template <class M, int RM>
+__global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, int which) {
+  constexpr int X = M::X, V = M::V, Z = M::Z, U = M::Z, V0 = M::V0, NXI = M::NXI;
+  constexpr int URM = RM <= 8 ? 64 : 1;
+  __shared__ double sm[4][RM * RM + RM * Z];
+  const int lane = threadIdx.x & 63;
+  const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wid = blockIdx.x * 4 + wv_;
+  if (wid >= sy.B * sy.K) return;
+  const int c = wid / sy.K, b = wid - c * sy.K;
+  if (!w.ok[c]) return;
+  const BlockDesc bd = sy.blk[b];
+  const int s_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int S = sy.S, NV = sy.NV;
+  const size_t TS = (size_t)sy.T * S;
+  const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* Jv = pick(sl.Jv, s_) + (size_t)c * RM * NV;
+  const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
+  const double* Xd = w.Xd + (size_t)c * RM * X * TS + bd.step0;
+  double* gv = pick(sl.grad, s_) + (size_t)c * sy.Q + sy.U;
+  double* Mb = sm[wv_];
+  double* zd = sm[wv_] + RM * RM;
+  for (int i = lane; i < RM * RM; i += 64) Mb[i] = w.gMb[cb * RM * RM + i];
+  for (int i = lane; i < RM * Z; i += 64) zd[i] = w.gzd[cb * RM * Z + i];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  double Lam[RM * X], xb[X], zbt[Z];
+#pragma unroll URM
+  for (int i = 0; i < RM * X; ++i) Lam[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < X; ++i) xb[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < Z; ++i) zbt[i] = 0.0;
+  const int ntile = (S + 63) >> 6;
+  for (int j = bd.nobs - 1; j >= 0; --j) {
+    if (j < bd.ny) {
+      double g[X], hv[X], xt[X];
+      for (int a = 0; a < X; ++a) xt[a] = w.gxdt[(cb * RM + j) * X + a];
+      M::obs_grad(traj + (size_t)(j + 1) * S * X, g);
+      M::obs_hess_vec(traj + (size_t)(j + 1) * S * X, xt, hv);
+#pragma unroll URM
+      for (int i = 0; i < RM; ++i)
+        if (i == j)
+#pragma unroll
+          for (int a = 0; a < X; ++a) Lam[i * X + a] = g[a];
+#pragma unroll
+      for (int a = 0; a < X; ++a) xb[a] += hv[a];
+    }
+    if (j == bd.nobs - 1 && !bd.last) {
+#pragma unroll URM
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int a = 0; a < X; ++a)
+          if (i == bd.ny + a) Lam[i * X + a] = 1.0;
+    }
+    for (int t = ntile - 1; t >= 0; --t) {
+      const int off = (t << 6) + lane;
+      const bool valid = off < S;
+      const int s = j * S + off;
+      const size_t col = colb + (size_t)s * V;
+      double A[X * X], Bm[X * V], Zf[X * Z], x[X], vv[V];
+      if (valid) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) x[a] = traj[(size_t)s * X + a];
+#pragma unroll
+        for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
+        M::jac(cc.k, x, vv, A, Bm, Zf);
+      } else {
+#pragma unroll
+        for (int a = 0; a < X; ++a) x[a] = 0.0;
+#pragma unroll
+        for (int a = 0; a < V; ++a) vv[a] = 0.0;
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+      }
+      // matrix suffix scan (adjoint rows)
+      double Inc[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        double Y[X * X], Pn[X * X];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o, 64);
+        matmul_xx<X>(Y, Inc, Pn);
+        if (lane + o < 64) {
+#pragma unroll
+          for (int i = 0; i < X * X; ++i) Inc[i] = Pn[i];
+        }
+      }
+      double E[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) {
+        const double y = __shfl_down(Inc[i], 1, 64);
+        E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
+      }
+      // Hessian contraction source of this step
+      double H[NXI];
+      {
+        double Sm[X * NXI];
+#pragma unroll
+        for (int i = 0; i < X * NXI; ++i) Sm[i] = 0.0;
+        double jp[RM * V];
+#pragma unroll URM
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int d = 0; d < V; ++d) jp[i * V + d] = valid ? Jv[(size_t)i * NV + col + d] : 0.0;
+#pragma unroll URM
+        for (int i = 0; i < RM; ++i) {
+          double Ls[X], dir[NXI];
+#pragma unroll
+          for (int d = 0; d < X; ++d) {
+            double tt = 0.0;
+#pragma unroll
+            for (int a = 0; a < X; ++a) tt += Lam[i * X + a] * E[a * X + d];
+            Ls[d] = tt;
+          }
+#pragma unroll
+          for (int a = 0; a < X; ++a) dir[a] = valid ? Xd[(size_t)(i * X + a) * TS + s] : 0.0;
+#pragma unroll
+          for (int d = 0; d < V; ++d) {
+            double tt = 0.0;
+#pragma unroll URM
+            for (int jj = 0; jj < RM; ++jj) tt += Mb[i * RM + jj] * jp[jj * V + d];
+            dir[X + d] = tt;
+          }
+#pragma unroll
+          for (int mz = 0; mz < Z; ++mz) dir[X + V + mz] = zd[i * Z + mz];
+#pragma unroll
+          for (int a = 0; a < X; ++a)
+#pragma unroll
+            for (int m2 = 0; m2 < NXI; ++m2) Sm[a * NXI + m2] += Ls[a] * dir[m2];
+        }
+        M::hess(cc.k, x, vv, Sm, H);
+        if (!valid) {
+#pragma unroll
+          for (int i = 0; i < NXI; ++i) H[i] = 0.0;
+        }
+      }
+      // joint suffix scan for x-bar: x-bar^(l) = x-bar^(l+1) A_l + Hx_l
+      double I2[X * X], gi[X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) I2[i] = A[i];
+#pragma unroll
+      for (int a = 0; a < X; ++a) gi[a] = H[a];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        double Y[X * X], gp[X], Pn[X * X];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(I2[i], o, 64);
+#pragma unroll
+        for (int a = 0; a < X; ++a) gp[a] = __shfl_down(gi[a], o, 64);
+        if (lane + o < 64) {
+#pragma unroll
+          for (int d = 0; d < X; ++d) {
+            double tt = gi[d];
+#pragma unroll
+            for (int a = 0; a < X; ++a) tt += gp[a] * I2[a * X + d];
+            gi[d] = tt;
+          }
+          matmul_xx<X>(Y, I2, Pn);
+#pragma unroll
+          for (int i = 0; i < X * X; ++i) I2[i] = Pn[i];
+        }
+      }
+      double xbs[X];  // x-bar at the state after this lane's step
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        const double ge = __shfl_down(gi[d], 1, 64);
+        double tt = lane == 63 ? 0.0 : ge;
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += xb[a] * E[a * X + d];
+        xbs[d] = tt;
+      }
+      if (valid) {
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          double tt = H[X + d];
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt += Bm[a * V + d] * xbs[a];
+          gv[col + d] = tt;
+        }
+      }
+#pragma unroll
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt = H[X + V + mz];
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += Zf[a * Z + mz] * xbs[a];
+        zbt[mz] += tt;
+      }
+      // carries
+      double I0[X * X], g0[X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) I0[i] = bcast0(I2[i]);
+#pragma unroll
+      for (int a = 0; a < X; ++a) g0[a] = bcast0(gi[a]);
+      {
+        double nb[X];
+#pragma unroll
+        for (int d = 0; d < X; ++d) {
+          double tt = g0[d];
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt += xb[a] * I0[a * X + d];
+          nb[d] = tt;
+        }
+#pragma unroll
+        for (int d = 0; d < X; ++d) xb[d] = nb[d];
+      }
+#pragma unroll URM
+      for (int i = 0; i < RM; ++i) {
+        double nl[X];
+#pragma unroll
+        for (int d = 0; d < X; ++d) {
+          double tt = 0.0;
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt += Lam[i * X + a] * I0[a * X + d];
+          nl[d] = tt;
+        }
+#pragma unroll
+        for (int d = 0; d < X; ++d) Lam[i * X + d] = nl[d];
+      }
+    }
+  }
+  if (bd.first && lane == 0) {
+    double dz[X * Z], dv0[X * V0];
+    M::gx0_jac(dz, dv0);
+    for (int d = 0; d < V0; ++d) {
+      double tt = 0.0;
+      for (int a = 0; a < X; ++a) tt += dv0[a * V0 + d] * xb[a];
+      gv[d] = tt;
+    }
+    for (int mz = 0; mz < Z; ++mz) {
+      double tt = 0.0;
+      for (int a = 0; a < X; ++a) tt += dz[a * Z + mz] * xb[a];
+      zbt[mz] += tt;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < Z; ++i) {
+    double v = zbt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    zbt[i] = v;
+  }
+  if (lane == 0) {
+    double Gz[Z * Z], gu[U];
+    M::gz_jac(q, Gz);
+    for (int d = 0; d < U; ++d) {
+      double tt = 0.0;
+      for (int mz = 0; mz < Z; ++mz) tt += Gz[mz * Z + d] * zbt[mz];
+      gu[d] = tt;
+    }
+    for (int i = 0; i < RM; ++i) {
+      double o[Z], wu[U], zb[Z];
+      for (int d = 0; d < U; ++d) wu[d] = w.gWu[(cb * RM + i) * U + d];
+      for (int mz = 0; mz < Z; ++mz) zb[mz] = w.zbP[(cb * RM + i) * Z + mz];
+      M::gz_hess(q, wu, zb, o);
+      for (int d = 0; d < U; ++d) gu[d] += o[d];
+    }
+    for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
+  }
+}
+
+}  // namespace chmc

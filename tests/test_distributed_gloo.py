@@ -1,0 +1,53 @@
+"""Multi-process path on CPU: world_size 2 over gloo.  Chains are sharded contiguously, each rank steps its shard
+with no communication, and one gather collects the samples; the result must equal the single-process run chain
+for chain (bitwise: chains are independent and every chain has its own generator)."""
+import os
+import socket
+import subprocess
+import sys
+import numpy as np
+import pytest
+from test_emu_logic import emu_lib  # noqa: F401
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("total", [6, 5])
+def test_two_ranks_equal_one_rank(emu_lib, tmp_path, total):  # noqa: F811
+    import dist_worker
+    single = dist_worker.run(total, 2, 0, 1)
+    out = str(tmp_path / "gathered.npy")
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), out, str(total), "2"],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise
+        assert p.returncode == 0, o.decode()[-2000:]
+    gathered = np.load(out)
+    assert gathered.shape == single.shape
+    np.testing.assert_array_equal(gathered, single)
+
+
+def test_shard_chains():
+    from manifold_mcmc_for_diffusions_amd.distributed import shard_chains
+    for total in (1, 7, 256, 1024, 4096):
+        for world in (1, 2, 4, 8):
+            spans = [shard_chains(total, r, world) for r in range(world)]
+            assert sum(c for _, c in spans) == total
+            assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(world - 1))

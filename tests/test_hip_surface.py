@@ -1,0 +1,65 @@
+"""GPU: the Mici-style surface end to end on the HIP library (one chain, exceptions; a batch, statuses) and the
+full-size properties of BASELINE.json configs[1] driven through the workload helper bench.py uses."""
+import numpy as np
+import pytest
+import manifold_mcmc_for_diffusions_amd as mm
+from manifold_mcmc_for_diffusions_amd import example_models as em
+
+pytestmark = pytest.mark.gpu
+TOLS = dict(constraint_tol=1e-9, position_tol=1e-8, max_iters=50)
+
+
+def test_reference_style_script_single_chain():
+    """The wiring of scripts/utils.py:254-290 + fhn_model_noisy_obs_chmc_experiment.py:105-117, with this package."""
+    from oracle.py import models as omodels, system as osys
+    rng = np.random.default_rng(20200710)
+    y = em.simulate_fhn_observations(10, 0.2, 200, seed=1, sigma=0.1)
+    system = mm.ConditionedDiffusionConstrainedSystem(
+        0.2, 10, 5, y, em.fhn.dim_z, em.fhn.dim_x, em.fhn.dim_v, em.fhn.forward_func, em.fhn.generate_x_0,
+        em.fhn.generate_z, em.fhn.obs_func, generate_σ=0.1, use_gaussian_splitting=False, dim_v_0=em.fhn.dim_v_0)
+    integrator = mm.ConstrainedLeapfrogIntegrator(
+        system, n_inner_step=1, projection_solver=mm.jitted_solve_projection_onto_manifold_newton,
+        reverse_check_tol=2e-8, projection_solver_kwargs=TOLS)
+    integrator.step_size = 0.05
+    gen = lambda r: np.concatenate((y, r.standard_normal(y.shape) * 0.5), -1)  # noqa: E731
+    u, v_0 = rng.standard_normal(4), rng.standard_normal(2)
+    state = mm.find_initial_state_by_linear_interpolation(system, rng, gen, u=u, v_0=v_0)
+    assert abs(system.constr(state)).max() < 1e-9
+    ref = osys.make_system(omodels.fhn, 0.2, 10, 5, y, sigma=0.1)
+    rstate = osys.ConditionedDiffusionHamiltonianState(state.pos, state.x_obs_seq, 0, mom=state.mom)
+    rinteg = osys.ConstrainedLeapfrogIntegrator(ref, step_size=0.05, projection_solver_kwargs=TOLS)
+    switch, rswitch = mm.SwitchPartitionTransition(system), osys.SwitchPartitionTransition(ref)
+    for it in range(2):
+        for _ in range(2):
+            state, rstate = integrator.step(state), rinteg.step(rstate)
+        np.testing.assert_allclose(state.pos, rstate.pos, atol=1e-8)
+        np.testing.assert_allclose(state.mom, rstate.mom, atol=1e-7)
+        assert abs(system.h(state) - ref.h(rstate)) < 1e-7 * abs(ref.h(rstate))
+        state, _ = switch.sample(state)
+        rstate, _ = rswitch.sample(rstate)
+        np.testing.assert_allclose(state.x_obs_seq, rstate.x_obs_seq, atol=1e-9)
+    integrator.step_size = 10.0
+    with pytest.raises((mm.ConvergenceError, mm.NonReversibleStepError)):
+        integrator.step(state)
+
+
+def test_workload_full_size_invariants_and_device_momentum():
+    import torch
+    from manifold_mcmc_for_diffusions_amd.workload import FhnWorkload
+    wl = FhnWorkload(8, num_steps_per_obs=400)
+    ctx = wl.ctx
+    assert ctx.Q == 80106
+    assert np.abs(ctx.constr()).max() < 1e-9  # linear-interpolation initial states lie on the manifold
+    dev = torch.device("cuda:0")
+    wl.refresh_momentum_device(torch, dev)
+    _, p, _, _ = ctx.get_state()
+    assert np.abs(ctx.lmult_by_jacob_constr(p)).max() < 1e-8 * np.abs(p).max() * np.sqrt(ctx.Q)
+    h0 = ctx.hamiltonian()[:, 0]
+    r = wl.step(0.02)
+    assert (r["status"] == 0).all() and np.abs(ctx.constr()).max() < 1e-9
+    assert np.isfinite(ctx.hamiltonian()).all() and (ctx.hamiltonian()[:, 0] != h0).all()
+    qd = torch.empty((8, ctx.Q), dtype=torch.float64, device=dev)
+    ctx.get_state_device(qd.data_ptr(), None)
+    q, _, _, _ = ctx.get_state()
+    assert np.array_equal(qd.cpu().numpy(), q)
+    ctx.close()
