@@ -117,7 +117,7 @@ int chmc_get_counters(const chmc_ctx* ctx, long long* out8);
  * (Jacobian store + Gram + Cholesky), 3 grad_log_det_blk, 4 update (J^T lambda column pass), 5 solve_chain,
  * 6 jacob_vec (J w), 7 constr (forward scan only), 8 element-wise, 9 sym_blk */
 #define CHMC_NUM_KERNEL_CLASSES 10
-int chmc_profile_enable(int on);                        /* start / stop recording (resets the accumulators) */
+int chmc_profile_enable(int on);  /* 0 stop, 1 all classes, else bit mask (1 << class); resets the accumulators */
 int chmc_profile_get(double* ms, long long* launches);  /* [CHMC_NUM_KERNEL_CLASSES] each; synchronises */
 
 #ifdef __cplusplus

@@ -82,7 +82,8 @@ struct ProfRec {
   hipEvent_t a, b;
   int cls;
 };
-static bool g_prof_on = false;
+static unsigned g_prof_mask = 0;  // bit per kernel class
+#define g_prof_on_for(cls) ((g_prof_mask >> (cls)) & 1u)
 static std::vector<ProfRec> g_prof_pending;
 static std::vector<hipEvent_t> g_prof_pool;
 static double g_prof_ms[16];
@@ -116,13 +117,14 @@ static void launch(F f, long n, int cls = 0) {
   const int bs = n >= 65536 ? 256 : 64;
   const unsigned grid = (unsigned)((n + bs - 1) / bs);
   ProfRec r;
-  if (g_prof_on) {
+  const bool prof = g_prof_on_for(cls);
+  if (prof) {
     r.a = prof_event(), r.b = prof_event(), r.cls = cls;
     note(hipEventRecord(r.a, g_stream));
   }
   hipLaunchKernelGGL(k_run<F>, dim3(grid), dim3(bs), 0, g_stream, f, (int)n);
   note(hipGetLastError());
-  if (g_prof_on) {
+  if (prof) {
     note(hipEventRecord(r.b, g_stream));
     g_prof_pending.push_back(r);
     if (g_prof_pending.size() > 4096) prof_drain();
@@ -154,13 +156,14 @@ template <class F>
 static void launch_colmax(F f, int ncol, int B, int cls = 0) {
   if (ncol <= 0 || B <= 0) return;
   ProfRec r;
-  if (g_prof_on) {
+  const bool prof = g_prof_on_for(cls);
+  if (prof) {
     r.a = prof_event(), r.b = prof_event(), r.cls = cls;
     note(hipEventRecord(r.a, g_stream));
   }
   hipLaunchKernelGGL(k_colmax<F>, dim3((unsigned)((ncol + 255) / 256), (unsigned)B), dim3(256), 0, g_stream, f, ncol);
   note(hipGetLastError());
-  if (g_prof_on) {
+  if (prof) {
     note(hipEventRecord(r.b, g_stream));
     g_prof_pending.push_back(r);
     if (g_prof_pending.size() > 4096) prof_drain();
@@ -171,13 +174,14 @@ template <class K, class... Args>
 static void launch_wave(K kern, long nwaves, int cls, Args... args) {
   if (nwaves <= 0) return;
   ProfRec r;
-  if (g_prof_on) {
+  const bool prof = g_prof_on_for(cls);
+  if (prof) {
     r.a = prof_event(), r.b = prof_event(), r.cls = cls;
     note(hipEventRecord(r.a, g_stream));
   }
   hipLaunchKernelGGL(kern, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, g_stream, args...);
   note(hipGetLastError());
-  if (g_prof_on) {
+  if (prof) {
     note(hipEventRecord(r.b, g_stream));
     g_prof_pending.push_back(r);
     if (g_prof_pending.size() > 4096) prof_drain();
@@ -186,7 +190,7 @@ static void launch_wave(K kern, long nwaves, int cls, Args... args) {
 extern "C" int chmc_profile_enable(int on) {
   if (g_stream) prof_drain();
   for (int i = 0; i < 16; ++i) g_prof_ms[i] = 0.0, g_prof_n[i] = 0;
-  g_prof_on = on != 0;
+  g_prof_mask = on == 1 ? 0xffffffffu : (unsigned)on;  // 1: every class; otherwise a bit mask of classes
   return 0;
 }
 extern "C" int chmc_profile_get(double* ms, long long* launches) {

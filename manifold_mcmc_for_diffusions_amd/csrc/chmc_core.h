@@ -273,11 +273,13 @@ struct ChainConsts {
 
 // One block of `constr` (:473-519): generate_y_bar (:399-411) minus y_bar (:447-470).
 // traj (may be null) receives nsteps+1 states; cp receives RM padded constraint values.
-// The recursion is inherently sequential; the noise increments of the next 8 steps are loaded while the current
-// 8 are integrated so that the dependent arithmetic chain, not memory latency, paces the scan.
-template <class M, int RM>
-CHMC_HD inline void fwd_block(const Sys& sy, const BlockDesc& bd, const ChainConsts<M>& cc, const double* q,
-                              const double* xobs, double* traj, double* cp) {
+// The recursion is inherently sequential: what paces it is the dependent FMA chain of one step, so the loop is
+// organised in tiles of 8 steps with (i) the noise increments of the next tile requested while the current one
+// is integrated and (ii) no per-step branches when S is a multiple of 8 (bounds, trajectory store and the
+// observation test are hoisted to tile level).
+template <class M, int RM, bool STORE>
+CHMC_HD inline void fwd_block_impl(const Sys& sy, const BlockDesc& bd, const ChainConsts<M>& cc, const double* q,
+                                   const double* xobs, double* traj, double* cp) {
   constexpr int X = M::X, V = M::V, PF = 8;
   double x[X], xn[X];
   const double* vb = q + sy.U;
@@ -289,43 +291,85 @@ CHMC_HD inline void fwd_block(const Sys& sy, const BlockDesc& bd, const ChainCon
   const double* v = vb + sy.V0 + (size_t)bd.step0 * V;
   const double* n = q + sy.U + sy.NV;
   for (int i = 0; i < RM; ++i) cp[i] = 0.0;
-  const int L = bd.nsteps;
+  const int L = bd.nsteps, S = sy.S;
   // loads run up to PF steps past the block's end (never consumed): every q-like buffer is allocated with
   // CHMC_Q_PAD doubles of slack so that the scan needs no per-element bounds branches
   double cur[PF * V], nxt[PF * V];
   CHMC_UNROLL
   for (int i = 0; i < PF * V; ++i) cur[i] = v[i];
-  int cnt = sy.S, j = 0;
-  for (int s0 = 0; s0 < L; s0 += PF) {
-    const double* vn = v + (size_t)(s0 + PF) * V;
-    CHMC_UNROLL
-    for (int i = 0; i < PF * V; ++i) nxt[i] = vn[i];
-    CHMC_UNROLL
-    for (int i = 0; i < PF; ++i) {
-      const int s = s0 + i;
-      if (s < L) {
-        if (traj)
-          for (int a = 0; a < X; ++a) traj[(size_t)s * X + a] = x[a];
+  if (S % PF == 0) {
+    int left = S, j = 0;  // steps left until the next observation time
+    for (int s0 = 0; s0 < L; s0 += PF) {
+      const double* vn = v + (size_t)(s0 + PF) * V;
+      CHMC_UNROLL
+      for (int i = 0; i < PF * V; ++i) nxt[i] = vn[i];
+      double tb[PF * X];
+      CHMC_UNROLL
+      for (int i = 0; i < PF; ++i) {
+        CHMC_UNROLL
+        for (int a = 0; a < X; ++a) tb[i * X + a] = x[a];
         M::step(cc.k, x, cur + i * V, xn);
+        CHMC_UNROLL
         for (int a = 0; a < X; ++a) x[a] = xn[a];
-        if (--cnt == 0) {  // s + 1 is the time of local observation j
-          if (j < bd.ny) {
-            double yv = M::obs(x);
-            if (sy.noisy) yv += sy.sigma * n[bd.obs0 + j];
-            cp[j] = yv - sy.y[bd.obs0 + j];
+      }
+      if (STORE) {
+        CHMC_UNROLL
+        for (int i = 0; i < PF * X; ++i) traj[(size_t)s0 * X + i] = tb[i];
+      }
+      left -= PF;
+      if (left == 0) {  // s0 + PF is the time of local observation j
+        if (j < bd.ny) {
+          double yv = M::obs(x);
+          if (sy.noisy) yv += sy.sigma * n[bd.obs0 + j];
+          cp[j] = yv - sy.y[bd.obs0 + j];
+        }
+        ++j;
+        left = S;
+      }
+      CHMC_UNROLL
+      for (int i = 0; i < PF * V; ++i) cur[i] = nxt[i];
+    }
+  } else {
+    int cnt = S, j = 0;
+    for (int s0 = 0; s0 < L; s0 += PF) {
+      const double* vn = v + (size_t)(s0 + PF) * V;
+      CHMC_UNROLL
+      for (int i = 0; i < PF * V; ++i) nxt[i] = vn[i];
+      CHMC_UNROLL
+      for (int i = 0; i < PF; ++i) {
+        const int s = s0 + i;
+        if (s < L) {
+          if (STORE)
+            for (int a = 0; a < X; ++a) traj[(size_t)s * X + a] = x[a];
+          M::step(cc.k, x, cur + i * V, xn);
+          for (int a = 0; a < X; ++a) x[a] = xn[a];
+          if (--cnt == 0) {  // s + 1 is the time of local observation j
+            if (j < bd.ny) {
+              double yv = M::obs(x);
+              if (sy.noisy) yv += sy.sigma * n[bd.obs0 + j];
+              cp[j] = yv - sy.y[bd.obs0 + j];
+            }
+            ++j;
+            cnt = S;
           }
-          ++j;
-          cnt = sy.S;
         }
       }
+      CHMC_UNROLL
+      for (int i = 0; i < PF * V; ++i) cur[i] = nxt[i];
     }
-    CHMC_UNROLL
-    for (int i = 0; i < PF * V; ++i) cur[i] = nxt[i];
   }
-  if (traj)
+  if (STORE)
     for (int a = 0; a < X; ++a) traj[(size_t)L * X + a] = x[a];
   if (!bd.last)
     for (int a = 0; a < X; ++a) cp[bd.ny + a] = x[a] - xobs[(bd.obs0 + bd.nobs - 1) * X + a];
+}
+template <class M, int RM>
+CHMC_HD inline void fwd_block(const Sys& sy, const BlockDesc& bd, const ChainConsts<M>& cc, const double* q,
+                              const double* xobs, double* traj, double* cp) {
+  if (traj)
+    fwd_block_impl<M, RM, true>(sy, bd, cc, q, xobs, traj, cp);
+  else
+    fwd_block_impl<M, RM, false>(sy, bd, cc, q, xobs, traj, cp);
 }
 
 // Reverse (adjoint) sweep over a block carrying all RM constraint rows (jacob_constr_blocks :521-624).

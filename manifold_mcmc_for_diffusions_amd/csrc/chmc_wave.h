@@ -39,6 +39,123 @@ __device__ inline void matmul_xx(const double* a, const double* b, double* c) { 
     }
 }
 
+// One 64-step tile of the reverse sweep with the rows i < J0 known to be structurally zero (observation row i of
+// a block vanishes in the intervals after its own observation time): J0 is a compile-time bound so the row loops
+// stay fully unrolled without run-time predicates.
+template <class M, int RM, int MODE, int J0>
+__device__ __forceinline__ void rev_tile(const ChainConsts<M>& cc, const int lane, const bool valid, const int s,
+                                         const double* cx, const double* cv, const double* cjp, double* Lam,
+                                         double* Dacc, double* zacc, double* Jo, const size_t colb, const int NV) {
+  constexpr int X = M::X, V = M::V, Z = M::Z;
+  double A[X * X], Bm[X * V], Zf[X * Z];
+
+      if (valid) {
+        M::jac(cc.k, cx, cv, A, Bm, Zf);
+      } else {
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+      }
+      // inclusive suffix scan: Inc_l = A_{hi} ... A_{l}  (later steps on the left)
+      double Inc[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        double Y[X * X], P[X * X];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o, 64);
+        matmul_xx<X>(Y, Inc, P);
+        if (lane + o < 64) {
+#pragma unroll
+          for (int i = 0; i < X * X; ++i) Inc[i] = P[i];
+        }
+      }
+      double E[X * X];  // exclusive: product over the later lanes only
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) {
+        const double y = __shfl_down(Inc[i], 1, 64);
+        E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
+      }
+      double Ls[RM * X], jr[RM * V];
+#pragma unroll
+      for (int i = J0; i < RM; ++i) {
+#pragma unroll
+        for (int d = 0; d < X; ++d) {
+          double tt2 = 0.0;
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt2 += Lam[i * X + a] * E[a * X + d];
+          Ls[i * X + d] = tt2;
+        }
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          double tt2 = 0.0;
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * Bm[a * V + d];
+          jr[i * V + d] = tt2;
+        }
+#pragma unroll
+        for (int mz = 0; mz < Z; ++mz) {
+          double tt2 = zacc[i * Z + mz];
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * Zf[a * Z + mz];
+          zacc[i * Z + mz] = tt2;
+        }
+      }
+      const size_t col = colb + (size_t)s * V;
+      if (MODE == 0) {
+        if (valid) {
+#pragma unroll
+          for (int i = 0; i < J0; ++i)  // structural zeros are stored explicitly (the row-slot layout is dense)
+#pragma unroll
+            for (int d = 0; d < V; ++d) Jo[(size_t)i * NV + col + d] = 0.0;
+#pragma unroll
+          for (int i = J0; i < RM; ++i)
+#pragma unroll
+            for (int d = 0; d < V; ++d) Jo[(size_t)i * NV + col + d] = jr[i * V + d];
+        }
+#pragma unroll
+        for (int i = J0; i < RM; ++i)
+#pragma unroll
+          for (int jj = J0; jj <= i; ++jj) {
+            double tt2 = Dacc[i * RM + jj];
+#pragma unroll
+            for (int d = 0; d < V; ++d) tt2 += jr[i * V + d] * jr[jj * V + d];
+            Dacc[i * RM + jj] = tt2;
+          }
+      } else {
+#pragma unroll
+        for (int i = J0; i < RM; ++i)
+#pragma unroll
+          for (int jj = J0; jj < RM; ++jj) {
+            double tt2 = Dacc[i * RM + jj];
+#pragma unroll
+            for (int d = 0; d < V; ++d) tt2 += jr[i * V + d] * cjp[jj * V + d];
+            Dacc[i * RM + jj] = tt2;
+          }
+      }
+      // carry the adjoint rows to the start of this tile: Lam <- Lam Inc_0
+      double I0[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) I0[i] = bcast0(Inc[i]);
+#pragma unroll
+      for (int i = J0; i < RM; ++i) {
+        double nl[X];
+#pragma unroll
+        for (int d = 0; d < X; ++d) {
+          double tt2 = 0.0;
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt2 += Lam[i * X + a] * I0[a * X + d];
+          nl[d] = tt2;
+        }
+#pragma unroll
+        for (int d = 0; d < X; ++d) Lam[i * X + d] = nl[d];
+      }
+    }
+
 // MODE 0: state evaluation -- store dc/dv rows, symmetric Gram, dc/du rows into the slot.
 // MODE 1: Newton iteration -- Gram of the iterate's rows against the stored rows of slot `which`.
 template <class M, int RM, int MODE>
@@ -132,112 +249,9 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
             if (i == bd.ny + a) Lam[i * X + a] = 1.0;
       }
     }
-    {
-      const bool valid = cvalid;
-      const int s = cs;
-      double A[X * X], Bm[X * V], Zf[X * Z];
-      if (valid) {
-        M::jac(cc.k, cx, cv, A, Bm, Zf);
-      } else {
-#pragma unroll
-        for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
-#pragma unroll
-        for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
-      }
-      // inclusive suffix scan: Inc_l = A_{hi} ... A_{l}  (later steps on the left)
-      double Inc[X * X];
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        double Y[X * X], P[X * X];
-#pragma unroll
-        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o, 64);
-        matmul_xx<X>(Y, Inc, P);
-        if (lane + o < 64) {
-#pragma unroll
-          for (int i = 0; i < X * X; ++i) Inc[i] = P[i];
-        }
-      }
-      double E[X * X];  // exclusive: product over the later lanes only
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) {
-        const double y = __shfl_down(Inc[i], 1, 64);
-        E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
-      }
-      double Ls[RM * X], jr[RM * V];
-#pragma unroll
-      for (int i = 0; i < RM; ++i) {
-#pragma unroll
-        for (int d = 0; d < X; ++d) {
-          double tt2 = 0.0;
-#pragma unroll
-          for (int a = 0; a < X; ++a) tt2 += Lam[i * X + a] * E[a * X + d];
-          Ls[i * X + d] = tt2;
-        }
-#pragma unroll
-        for (int d = 0; d < V; ++d) {
-          double tt2 = 0.0;
-#pragma unroll
-          for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * Bm[a * V + d];
-          jr[i * V + d] = tt2;
-        }
-#pragma unroll
-        for (int mz = 0; mz < Z; ++mz) {
-          double tt2 = zacc[i * Z + mz];
-#pragma unroll
-          for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * Zf[a * Z + mz];
-          zacc[i * Z + mz] = tt2;
-        }
-      }
-      const size_t col = colb + (size_t)s * V;
-      if (MODE == 0) {
-        if (valid) {
-#pragma unroll
-          for (int i = 0; i < RM; ++i)
-#pragma unroll
-            for (int d = 0; d < V; ++d) Jo[(size_t)i * NV + col + d] = jr[i * V + d];
-        }
-#pragma unroll
-        for (int i = 0; i < RM; ++i)
-#pragma unroll
-          for (int jj = 0; jj <= i; ++jj) {
-            double tt2 = Dacc[i * RM + jj];
-#pragma unroll
-            for (int d = 0; d < V; ++d) tt2 += jr[i * V + d] * jr[jj * V + d];
-            Dacc[i * RM + jj] = tt2;
-          }
-      } else {
-#pragma unroll
-        for (int i = 0; i < RM; ++i)
-#pragma unroll
-          for (int jj = 0; jj < RM; ++jj) {
-            double tt2 = Dacc[i * RM + jj];
-#pragma unroll
-            for (int d = 0; d < V; ++d) tt2 += jr[i * V + d] * cjp[jj * V + d];
-            Dacc[i * RM + jj] = tt2;
-          }
-      }
-      // carry the adjoint rows to the start of this tile: Lam <- Lam Inc_0
-      double I0[X * X];
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) I0[i] = bcast0(Inc[i]);
-#pragma unroll
-      for (int i = 0; i < RM; ++i) {
-        double nl[X];
-#pragma unroll
-        for (int d = 0; d < X; ++d) {
-          double tt2 = 0.0;
-#pragma unroll
-          for (int a = 0; a < X; ++a) tt2 += Lam[i * X + a] * I0[a * X + d];
-          nl[d] = tt2;
-        }
-#pragma unroll
-        for (int d = 0; d < X; ++d) Lam[i * X + d] = nl[d];
-      }
-    }
+    // (specialising the tile on the first structurally non-zero row -- rows i < j vanish in interval j -- was
+    // measured slower: eight unrolled copies of the tile body thrash the instruction cache)
+    rev_tile<M, RM, MODE, 0>(cc, lane, cvalid, cs, cx, cv, cjp, Lam, Dacc, zacc, Jo, colb, NV);
 #pragma unroll
     for (int a = 0; a < X; ++a) cx[a] = nx[a];
 #pragma unroll
