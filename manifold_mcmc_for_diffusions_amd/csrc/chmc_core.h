@@ -1230,10 +1230,14 @@ struct KSolveChain {
 };
 
 // Column-parallel part of J^T lambda (rmult_by_jacob_constr :879-913) fused with its consumer; a "column max"
-// kernel: work item (chain c, column col), the returned bit pattern is max-reduced per chain into *red(c)
+// kernel: work item (chain c, column group), the returned bit pattern is max-reduced per chain into *red(c)
 // by the launcher (wave shuffle + LDS, one atomic per workgroup -- 2e7 same-address atomics serialise).
 //  TGT 0: q -= d, mu += d, ndq = max |d|     TGT 1: p -= d     TGT 2: out = d (work.pb, all columns incl. u)
-template <int RM, int TGT>
+//  VEC 2: one work item handles two adjacent columns with 16-byte accesses (needs even Q, NV, U, V0, V).
+struct double2_ {
+  double x, y;
+};
+template <int RM, int TGT, int VEC>
 struct KUpdate {
   Sys sy;
   Slots sl;
@@ -1241,36 +1245,86 @@ struct KUpdate {
   int which, qsel, psel;
   CHMC_HD bool active(int c) const { return TGT == 0 ? w.nw[c] != 0 : w.ok[c] != 0; }
   CHMC_HD unsigned long long* red(int c) const { return TGT == 0 ? &w.ndq[c] : nullptr; }
-  CHMC_HD unsigned long long operator()(int c, int col) const {
+  CHMC_HD double ncol_part(int c, int col) const {  // observation-noise columns: dc/dn = sigma on y rows (:601-608)
+    const int t = col - sy.NV;
+    const int b = sy.obs2blk[t];
+    const int j = t - sy.blk[b].obs0;
+    return j < sy.blk[b].ny ? sy.sigma * w.lampad[((size_t)c * sy.Kmax + b) * RM + j] : 0.0;
+  }
+  CHMC_HD unsigned long long operator()(int c, int idx) const {
     const int s = sl.cur[c] ^ which;
-    double d;
+    const int col = idx * VEC;
+    const size_t qi = (size_t)c * sy.Q + sy.U + col;
+    double* tgt = TGT == 0 ? (qsel ? w.qb : pick(sl.q, s ^ 1))
+                           : TGT == 1 ? (psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : pick(sl.p, s ^ 1)) : w.pb;
+    double d[VEC], old[VEC], mu[VEC];
+    // issue the read-modify-write operands together with the Jacobian rows
+    if (TGT != 2) {
+      if (VEC == 2) {
+        const double2_ o = *reinterpret_cast<const double2_*>(tgt + qi);
+        old[0] = o.x, old[VEC - 1] = o.y;
+      } else {
+        old[0] = tgt[qi];
+      }
+    }
+    if (TGT == 0) {
+      if (VEC == 2) {
+        const double2_ o = *reinterpret_cast<const double2_*>(w.mu + qi);
+        mu[0] = o.x, mu[VEC - 1] = o.y;
+      } else {
+        mu[0] = w.mu[qi];
+      }
+    }
     if (col < sy.NV) {
-      int g = col < sy.V0 ? 0 : (col - sy.V0) / sy.V / sy.S;
+      const int g = col < sy.V0 ? 0 : (col - sy.V0) / sy.V / sy.S;
       const int b = sy.obs2blk[g];
       const double* lam = w.lampad + ((size_t)c * sy.Kmax + b) * RM;
       const double* Jv = pick(sl.Jv, s) + (size_t)c * RM * sy.NV + col;
-      d = 0.0;
       CHMC_UNROLL
-      for (int i = 0; i < RM; ++i) d += Jv[(size_t)i * sy.NV] * lam[i];
+      for (int k = 0; k < VEC; ++k) d[k] = 0.0;
+      // observation row i of a block is structurally zero in the intervals after its own observation, and slots
+      // beyond the block's row count are padding: only rows [m, nrows) are read
+      const int m = col < sy.V0 ? 0 : g - sy.blk[b].obs0;
+      const int nr = sy.blk[b].nrows;
+      CHMC_UNROLL
+      for (int i = 0; i < RM; ++i) {
+        if (i >= m && i < nr) {
+          if (VEC == 2) {
+            const double2_ jv = *reinterpret_cast<const double2_*>(Jv + (size_t)i * sy.NV);
+            d[0] += jv.x * lam[i];
+            d[VEC - 1] += jv.y * lam[i];
+          } else {
+            d[0] += Jv[(size_t)i * sy.NV] * lam[i];
+          }
+        }
+      }
     } else {
-      const int t = col - sy.NV;
-      const int b = sy.obs2blk[t];
-      const int j = t - sy.blk[b].obs0;
-      d = j < sy.blk[b].ny ? sy.sigma * w.lampad[((size_t)c * sy.Kmax + b) * RM + j] : 0.0;
+      CHMC_UNROLL
+      for (int k = 0; k < VEC; ++k) d[k] = ncol_part(c, col + k);
     }
-    const size_t qi = (size_t)c * sy.Q + sy.U + col;
-    if (TGT == 0) {
-      double* q = qsel ? w.qb : pick(sl.q, s ^ 1);
-      q[qi] -= d;
-      w.mu[qi] += d;
-      return absbits(d);
-    } else if (TGT == 1) {
-      double* p = psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : pick(sl.p, s ^ 1);
-      p[qi] -= d;
+    unsigned long long r = 0ULL;
+    CHMC_UNROLL
+    for (int k = 0; k < VEC; ++k) {
+      if (TGT == 0) {
+        const unsigned long long vb = absbits(d[k]);
+        r = vb > r ? vb : r;
+        mu[k] += d[k];
+      }
+      old[k] = TGT == 2 ? d[k] : old[k] - d[k];
+    }
+    if (VEC == 2) {
+      double2_ o;
+      o.x = old[0], o.y = old[VEC - 1];
+      *reinterpret_cast<double2_*>(tgt + qi) = o;
+      if (TGT == 0) {
+        o.x = mu[0], o.y = mu[VEC - 1];
+        *reinterpret_cast<double2_*>(w.mu + qi) = o;
+      }
     } else {
-      w.pb[qi] = d;
+      tgt[qi] = old[0];
+      if (TGT == 0) w.mu[qi] = mu[0];
     }
-    return 0ULL;
+    return r;
   }
 };
 

@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
       if (MODE == 1) {
         const size_t col = colb + (size_t)sidx * V;
 #pragma unroll
-        for (int i = 0; i < RM; ++i)
+        for (int i = 0; i < RM; ++i)  // (skipping the structurally zero rows here breaks the load pipelining: 2x slower)
 #pragma unroll
           for (int d = 0; d < V; ++d) jp[i * V + d] = Jr[(size_t)i * NV + col + d];
       }
@@ -360,10 +360,17 @@ __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int w
   double acc[RM];
 #pragma unroll
   for (int i = 0; i < RM; ++i) acc[i] = 0.0;
-  for (int k = lane; k < bd.ncols; k += 64) {
-    const double x = wv[k];
+  // interval m of the block: only rows [m, nrows) are non-zero there (v_0 columns belong to interval 0)
+  const int voff = bd.first ? sy.V0 : 0;
+  const int per = sy.S * sy.V;
+  for (int m = 0; m < bd.nobs; ++m) {
+    const int k0 = m == 0 ? 0 : voff + m * per, k1 = voff + (m + 1) * per;
+    for (int k = k0 + lane; k < k1; k += 64) {
+      const double x = wv[k];
 #pragma unroll
-    for (int i = 0; i < RM; ++i) acc[i] += Jv[(size_t)i * sy.NV + k] * x;
+      for (int i = 0; i < RM; ++i)
+        if (i >= m && i < bd.nrows) acc[i] += Jv[(size_t)i * sy.NV + k] * x;
+    }
   }
 #pragma unroll
   for (int i = 0; i < RM; ++i) {
@@ -850,6 +857,108 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
       for (int d = 0; d < U; ++d) gu[d] += o[d];
     }
     for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
+  }
+}
+
+// Chain part of the Woodbury solves (KSolveChain in chmc_core.h) with the blocks of a chain spread over the lanes
+// of one wavefront: lane b owns block b (K <= 64), the U x U core matrix and right-hand side are summed over the
+// lanes with shuffles, every lane solves the tiny core system redundantly, forms its block's multipliers and its
+// share of the u-columns of J^T lambda, which is reduced again.  Same template parameters as KSolveChain.
+template <class M, int RM, int SYM, int TGT>
+__global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work w, int which, int qsel, int psel) {
+  constexpr int U = M::Z;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (c >= sy.B) return;
+  if (TGT == 0 ? !w.nw[c] : !w.ok[c]) return;
+  const int s = sl.cur[c] ^ which;
+  const bool has = lane < sy.K;
+  const size_t cb = (size_t)c * sy.Kmax + (has ? lane : 0);
+  double sacc[U], Cm[U * U];
+#pragma unroll
+  for (int a = 0; a < U; ++a) sacc[a] = has ? w.sb[cb * U + a] : 0.0;
+  if (!SYM) {
+#pragma unroll
+    for (int i = 0; i < U * U; ++i) Cm[i] = has ? w.Cb[cb * U * U + i] : 0.0;
+  }
+#pragma unroll
+  for (int a = 0; a < U; ++a) {
+    double v = sacc[a];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    sacc[a] = v;
+  }
+  if (SYM) {
+    double Lc[U * U];
+#pragma unroll
+    for (int i = 0; i < U * U; ++i) Lc[i] = pick(sl.facC, s)[(size_t)c * U * U + i];
+    cho_solve<U, 1>(Lc, sacc);
+  } else {
+#pragma unroll
+    for (int i = 0; i < U * U; ++i) {
+      double v = Cm[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      Cm[i] = v + ((i / U == i % U) ? 1.0 : 0.0);  // + M_0 = I
+    }
+    int piv[U];
+    lu_factor<U>(Cm, piv);
+    lu_solve<U, 1>(Cm, piv, sacc);
+  }
+  double du[U];
+#pragma unroll
+  for (int a = 0; a < U; ++a) du[a] = 0.0;
+  unsigned long long eb = 0ULL;
+  if (has) {
+    const double* E = (SYM ? pick(sl.E, s) : w.Ew) + cb * RM * U;
+    const double* ju = pick(sl.JuP, s) + cb * RM * U;
+#pragma unroll
+    for (int i = 0; i < RM; ++i) {
+      double l = w.tpad[cb * RM + i];
+#pragma unroll
+      for (int a = 0; a < U; ++a) l -= E[i * U + a] * sacc[a];
+      w.lampad[cb * RM + i] = l;
+#pragma unroll
+      for (int a = 0; a < U; ++a) du[a] += ju[i * U + a] * l;
+      if (TGT == 0) {
+        const unsigned long long vb = absbits(w.cpad[cb * RM + i]);
+        eb = vb > eb ? vb : eb;
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < U; ++a) {
+    double v = du[a];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    du[a] = v;
+  }
+  if (TGT == 0) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long v = __shfl_xor(eb, o, 64);
+      eb = v > eb ? v : eb;
+    }
+  }
+  if (lane == 0) {
+    if (TGT == 0) {
+      double* q = (qsel ? w.qb : pick(sl.q, s ^ 1)) + (size_t)c * sy.Q;
+      double* mu = w.mu + (size_t)c * sy.Q;
+      unsigned long long nb = 0ULL;
+#pragma unroll
+      for (int a = 0; a < U; ++a) {
+        q[a] -= du[a];
+        mu[a] += du[a];
+        const unsigned long long vb = absbits(du[a]);
+        nb = vb > nb ? vb : nb;
+      }
+      w.err[c] = bitsd(eb);
+      w.ndq[c] = nb;
+    } else if (TGT == 1) {
+      double* p = (psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
+#pragma unroll
+      for (int a = 0; a < U; ++a) p[a] -= du[a];
+    }
   }
 }
 
