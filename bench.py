@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--burn-step-size", type=float, default=0.1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="record no HIP events in the timed region")
-    ap.add_argument("--cpu-steps", type=int, default=6)
+    ap.add_argument("--cpu-steps", type=int, default=250)
     return ap.parse_args()
 
 

@@ -468,10 +468,13 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
           for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
           M::jac(cc.k, x, vv, A, Bm, Zf);
           const size_t col = colb + (size_t)s * V;
+          // rows i < j (their observation lies before this interval) and padded slots are structurally zero
 #pragma unroll URM
-          for (int i = 0; i < RM; ++i)
+          for (int i = 0; i < RM; ++i) {
+            const bool act = i >= j && i < bd.nrows;
 #pragma unroll
-            for (int d = 0; d < V; ++d) jp[i * V + d] = Jv[(size_t)i * NV + col + d];
+            for (int d = 0; d < V; ++d) jp[i * V + d] = act ? Jv[(size_t)i * NV + col + d] : 0.0;
+          }
         } else {
 #pragma unroll
           for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
@@ -554,9 +557,13 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
             for (int d = 0; d < X; ++d) tt += Pex[a * X + d] * xdc[i * X + d];
             xs[i * X + a] = tt;
           }
-        if (valid) {
+        if (valid) {  // the tangent of row i is only needed up to that row's own observation time
 #pragma unroll URM
-          for (int i = 0; i < RM * X; ++i) Xd[(size_t)i * TS + s] = xs[i];
+          for (int i = 0; i < RM; ++i)
+            if (i >= j && i < bd.nrows) {
+#pragma unroll
+              for (int a = 0; a < X; ++a) Xd[(size_t)(i * X + a) * TS + s] = xs[i * X + a];
+            }
         }
       }
       // carry to the next tile: apply lane 63's inclusive map
@@ -701,9 +708,11 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
         for (int i = 0; i < X * NXI; ++i) Sm[i] = 0.0;
         double jp[RM * V];
 #pragma unroll URM
-        for (int i = 0; i < RM; ++i)
+        for (int i = 0; i < RM; ++i) {
+          const bool act = valid && i >= j && i < bd.nrows;
 #pragma unroll
-          for (int d = 0; d < V; ++d) jp[i * V + d] = valid ? Jv[(size_t)i * NV + col + d] : 0.0;
+          for (int d = 0; d < V; ++d) jp[i * V + d] = act ? Jv[(size_t)i * NV + col + d] : 0.0;
+        }
 #pragma unroll URM
         for (int i = 0; i < RM; ++i) {
           double Ls[X], dir[NXI];
@@ -715,7 +724,7 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
             Ls[d] = tt;
           }
 #pragma unroll
-          for (int a = 0; a < X; ++a) dir[a] = valid ? Xd[(size_t)(i * X + a) * TS + s] : 0.0;
+          for (int a = 0; a < X; ++a) dir[a] = (valid && i >= j && i < bd.nrows) ? Xd[(size_t)(i * X + a) * TS + s] : 0.0;
 #pragma unroll
           for (int d = 0; d < V; ++d) {
             double tt = 0.0;
