@@ -3,8 +3,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-static hipStream_t g_stream = nullptr;
-static int g_device = -1;
+// one stream per host thread that drives a context (contexts driven from different threads run concurrently)
+static thread_local hipStream_t g_stream = nullptr;
+static thread_local int g_device = -1;
 static hipError_t g_first_err = hipSuccess;
 
 static inline void note(hipError_t e) {

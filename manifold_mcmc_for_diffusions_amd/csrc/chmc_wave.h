@@ -971,4 +971,9 @@ __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work
   }
 }
 
+// (An LDS-staged variant of the forward scan -- 8 lanes fetching one block's 128-byte tile, tiles parked in LDS with a
+// 144-byte row stride, trajectory tiles written back the same way -- was built and measured at 2x the time of the
+// plain lane-per-block scan of chmc_core.h: with one wavefront per SIMD the extra LDS round trips sit on the
+// critical path of the sequential recursion.  It was removed.)
+
 }  // namespace chmc
