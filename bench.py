@@ -86,13 +86,14 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    devno = int(os.environ.get("CHMC_BENCH_DEVICE", local_rank))  # override only for single-GPU rehearsals
+    torch.cuda.set_device(devno)
+    dev = torch.device("cuda", devno)
     from manifold_mcmc_for_diffusions_amd import _lib
     from manifold_mcmc_for_diffusions_amd.workload import FhnWorkload
     L = _lib.lib()
     B = a.chains_per_gpu
-    wl = FhnWorkload(B, num_steps_per_obs=a.num_steps_per_obs, device=local_rank, chain_offset=rank * B,
+    wl = FhnWorkload(B, num_steps_per_obs=a.num_steps_per_obs, device=devno, chain_offset=rank * B,
                      total_chains=world * B)
     ctx = wl.ctx
 

@@ -17,14 +17,15 @@ def init_process_group(backend=None):
         import torch
         import torch.distributed as dist
         if not dist.is_initialized():
-            if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+            if backend is None:  # CHMC_DIST_BACKEND=gloo: CPU-collective rehearsal of the multi-rank path
+                backend = os.environ.get("CHMC_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
             kw = {}
             if backend == "nccl":
-                torch.cuda.set_device(local_rank)
-                kw["device_id"] = torch.device("cuda", local_rank)
+                dev = int(os.environ.get("CHMC_BENCH_DEVICE", local_rank))
+                torch.cuda.set_device(dev)
+                kw["device_id"] = torch.device("cuda", dev)
             dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
@@ -54,6 +55,8 @@ def gather_samples(local, dst=0):
     t = local if isinstance(local, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local))
     if backend == "nccl" and not t.is_cuda:
         t = t.cuda()
+    if backend == "gloo" and t.is_cuda:
+        t = t.cpu()
     world, rank = dist.get_world_size(), dist.get_rank()
     counts = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
     dist.all_gather(counts, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device))

@@ -87,6 +87,26 @@ def test_baseline_config3_size_fhn_noiseless_s400():
     ctx.close()
 
 
+def test_baseline_config4_size_sir_s200():
+    """Full-size shape of BASELINE.json configs[3]: SIR, T = 14, S = 200, R = 14 (one dense 14-row block, Q = 8419);
+    synthetic data from the prior (the boarding-school counts need the Adam initialiser, SURVEY.md 8f #1)."""
+    case = make_case("sir", 14, 200, 14, True, B=2, seed=19, obs_interval=0.25)
+    ctx = make_ctx(case)
+    assert ctx.Q == 8419 and ctx.C == [14] and ctx.K == [1] and ctx.RM == 16
+    check_ops_against_oracle(ctx, case, tol=1e-9)
+    check_steps_against_oracle(ctx, case, np.array([0.02, -0.02]), n_steps=1)
+    ctx.close()
+
+
+def test_baseline_config5_size_fhn_noisy_s800():
+    """Full-size shape of BASELINE.json configs[4] (S = 800, Q = 160106), 2 chains, one step against the oracle."""
+    case = make_case("fhn", 100, 800, 5, True, B=2, seed=20)
+    ctx = make_ctx(case)
+    assert ctx.Q == 160106 and ctx.C == [138, 140]
+    check_steps_against_oracle(ctx, case, np.array([0.05, -0.05]), n_steps=1)
+    ctx.close()
+
+
 def test_size_independent_properties_full_size():
     """At full size: after a successful step |c|_inf < ctol, J p = 0 (momentum tangent), and a step followed by a
     direction flip returns to the start (reversibility, tolerance 2e-8 as reverse_check_tol)."""
