@@ -39,128 +39,14 @@ __device__ inline void matmul_xx(const double* a, const double* b, double* c) { 
     }
 }
 
-// One 64-step tile of the reverse sweep with the rows i < J0 known to be structurally zero (observation row i of
-// a block vanishes in the intervals after its own observation time): J0 is a compile-time bound so the row loops
-// stay fully unrolled without run-time predicates.
-template <class M, int RM, int MODE, int J0>
-__device__ __forceinline__ void rev_tile(const ChainConsts<M>& cc, const int lane, const bool valid, const int s,
-                                         const double* cx, const double* cv, const double* cjp, double* Lam,
-                                         double* Dacc, double* zacc, double* Jo, const size_t colb, const int NV) {
-  constexpr int X = M::X, V = M::V, Z = M::Z;
-  double A[X * X], Bm[X * V], Zf[X * Z];
-
-      if (valid) {
-        M::jac(cc.k, cx, cv, A, Bm, Zf);
-      } else {
-#pragma unroll
-        for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
-#pragma unroll
-        for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
-      }
-      // inclusive suffix scan: Inc_l = A_{hi} ... A_{l}  (later steps on the left)
-      double Inc[X * X];
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        double Y[X * X], P[X * X];
-#pragma unroll
-        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o, 64);
-        matmul_xx<X>(Y, Inc, P);
-        if (lane + o < 64) {
-#pragma unroll
-          for (int i = 0; i < X * X; ++i) Inc[i] = P[i];
-        }
-      }
-      double E[X * X];  // exclusive: product over the later lanes only
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) {
-        const double y = __shfl_down(Inc[i], 1, 64);
-        E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
-      }
-      double Ls[RM * X], jr[RM * V];
-#pragma unroll
-      for (int i = J0; i < RM; ++i) {
-#pragma unroll
-        for (int d = 0; d < X; ++d) {
-          double tt2 = 0.0;
-#pragma unroll
-          for (int a = 0; a < X; ++a) tt2 += Lam[i * X + a] * E[a * X + d];
-          Ls[i * X + d] = tt2;
-        }
-#pragma unroll
-        for (int d = 0; d < V; ++d) {
-          double tt2 = 0.0;
-#pragma unroll
-          for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * Bm[a * V + d];
-          jr[i * V + d] = tt2;
-        }
-#pragma unroll
-        for (int mz = 0; mz < Z; ++mz) {
-          double tt2 = zacc[i * Z + mz];
-#pragma unroll
-          for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * Zf[a * Z + mz];
-          zacc[i * Z + mz] = tt2;
-        }
-      }
-      const size_t col = colb + (size_t)s * V;
-      if (MODE == 0) {
-        if (valid) {
-#pragma unroll
-          for (int i = 0; i < J0; ++i)  // structural zeros are stored explicitly (the row-slot layout is dense)
-#pragma unroll
-            for (int d = 0; d < V; ++d) Jo[(size_t)i * NV + col + d] = 0.0;
-#pragma unroll
-          for (int i = J0; i < RM; ++i)
-#pragma unroll
-            for (int d = 0; d < V; ++d) Jo[(size_t)i * NV + col + d] = jr[i * V + d];
-        }
-#pragma unroll
-        for (int i = J0; i < RM; ++i)
-#pragma unroll
-          for (int jj = J0; jj <= i; ++jj) {
-            double tt2 = Dacc[i * RM + jj];
-#pragma unroll
-            for (int d = 0; d < V; ++d) tt2 += jr[i * V + d] * jr[jj * V + d];
-            Dacc[i * RM + jj] = tt2;
-          }
-      } else {
-#pragma unroll
-        for (int i = J0; i < RM; ++i)
-#pragma unroll
-          for (int jj = J0; jj < RM; ++jj) {
-            double tt2 = Dacc[i * RM + jj];
-#pragma unroll
-            for (int d = 0; d < V; ++d) tt2 += jr[i * V + d] * cjp[jj * V + d];
-            Dacc[i * RM + jj] = tt2;
-          }
-      }
-      // carry the adjoint rows to the start of this tile: Lam <- Lam Inc_0
-      double I0[X * X];
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) I0[i] = bcast0(Inc[i]);
-#pragma unroll
-      for (int i = J0; i < RM; ++i) {
-        double nl[X];
-#pragma unroll
-        for (int d = 0; d < X; ++d) {
-          double tt2 = 0.0;
-#pragma unroll
-          for (int a = 0; a < X; ++a) tt2 += Lam[i * X + a] * I0[a * X + d];
-          nl[d] = tt2;
-        }
-#pragma unroll
-        for (int d = 0; d < X; ++d) Lam[i * X + d] = nl[d];
-      }
-    }
-
 // MODE 0: state evaluation -- store dc/dv rows, symmetric Gram, dc/du rows into the slot.
 // MODE 1: Newton iteration -- Gram of the iterate's rows against the stored rows of slot `which`.
 template <class M, int RM, int MODE>
 __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int which, int qsel) {
   constexpr int X = M::X, V = M::V, Z = M::Z, U = M::Z, V0 = M::V0;
+  // the fully unrolled 16-row instantiation is mis-compiled by ROCm 7.2 under heavy register spilling (wrong dc/du);
+  // it keeps its row loops rolled, the <= 8-row instantiations are fully unrolled
+  constexpr int URM = RM <= 8 ? 64 : 1;
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= sy.B * sy.K) return;
@@ -180,88 +66,193 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
 
   double Lam[RM * X], Dacc[RM * RM], zacc[RM * Z];
-#pragma unroll
+#pragma unroll URM
   for (int i = 0; i < RM * X; ++i) Lam[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < RM * RM; ++i) Dacc[i] = 0.0;
-#pragma unroll
+#pragma unroll URM
   for (int i = 0; i < RM * Z; ++i) zacc[i] = 0.0;
 
-  // The tiles are walked backwards in time; the raw inputs of the NEXT tile (state, noise increment, stored rows)
-  // are requested before the current tile is processed, so their HBM latency overlaps the scan arithmetic
-  // (one wavefront per SIMD is resident at this register footprint, there is no other wave to hide it).
+  // The tiles are walked backwards in time as a two-stage software pipeline (one wavefront per SIMD is resident at
+  // this register footprint, so independent work must come from the wave itself):
+  //   stage 1 (tile t-1): transition matrices of the 64 steps and their suffix scan -- a chain of dependent shuffles;
+  //   stage 2 (tile t)  : adjoint rows at every lane (Lam E), Jacobian entries, dc/dz sums, Gram accumulation.
+  // Stage 1 of the next tile does not depend on the carried rows Lam, so both stages sit in one basic block and the
+  // scheduler fills the shuffle latencies of one with the FMAs of the other.  Raw inputs are requested two tiles
+  // ahead.
   const int ntile = (S + 63) >> 6;
   const int ntot = bd.nobs * ntile;
-  double cx[X], cv[V], cjp[RM * V];
-  bool cvalid;
-  int cs;
-  auto fetch = [&](int tt, double* x, double* vv, double* jp, bool& valid, int& sidx) {
+  struct Raw {
+    double x[X], v[V], jp[RM * V];
+    bool valid;
+    int s;
+  };
+  struct Scan {
+    double Bm[X * V], Zf[X * Z], E[X * X], I0[X * X];
+  };
+  auto fetch = [&](int tt, Raw& r) {
     const int jj = tt / ntile, t = tt - jj * ntile;
     const int off = (t << 6) + lane;
-    valid = off < S;
-    sidx = jj * S + off;
-    if (valid) {
+    r.valid = tt >= 0 && off < S;
+    r.s = jj * S + off;
+    if (r.valid) {
 #pragma unroll
-      for (int a = 0; a < X; ++a) x[a] = traj[(size_t)sidx * X + a];
+      for (int a = 0; a < X; ++a) r.x[a] = traj[(size_t)r.s * X + a];
 #pragma unroll
-      for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)sidx * V + a];
+      for (int a = 0; a < V; ++a) r.v[a] = vbase[(size_t)r.s * V + a];
       if (MODE == 1) {
-        const size_t col = colb + (size_t)sidx * V;
-#pragma unroll
+        const size_t col = colb + (size_t)r.s * V;
+#pragma unroll URM
         for (int i = 0; i < RM; ++i)  // (skipping the structurally zero rows here breaks the load pipelining: 2x slower)
 #pragma unroll
-          for (int d = 0; d < V; ++d) jp[i * V + d] = Jr[(size_t)i * NV + col + d];
+          for (int d = 0; d < V; ++d) r.jp[i * V + d] = Jr[(size_t)i * NV + col + d];
       }
     } else {
 #pragma unroll
-      for (int a = 0; a < X; ++a) x[a] = 0.0;
+      for (int a = 0; a < X; ++a) r.x[a] = 0.0;
 #pragma unroll
-      for (int a = 0; a < V; ++a) vv[a] = 0.0;
+      for (int a = 0; a < V; ++a) r.v[a] = 0.0;
       if (MODE == 1) {
-#pragma unroll
-        for (int i = 0; i < RM * V; ++i) jp[i] = 0.0;
+#pragma unroll URM
+        for (int i = 0; i < RM * V; ++i) r.jp[i] = 0.0;
       }
     }
   };
-  fetch(ntot - 1, cx, cv, cjp, cvalid, cs);
+  auto stage1 = [&](const Raw& r, Scan& o) {
+    double A[X * X];
+    if (r.valid) {
+      M::jac(cc.k, r.x, r.v, A, o.Bm, o.Zf);
+    } else {
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+      for (int i = 0; i < X * V; ++i) o.Bm[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < X * Z; ++i) o.Zf[i] = 0.0;
+    }
+    // inclusive suffix scan: Inc_l = A_{hi} ... A_{l}  (later steps on the left)
+    double Inc[X * X];
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
+#pragma unroll
+    for (int o2 = 1; o2 < 64; o2 <<= 1) {
+      double Y[X * X], P[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o2, 64);
+      matmul_xx<X>(Y, Inc, P);
+      if (lane + o2 < 64) {
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Inc[i] = P[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) {  // exclusive: product over the later lanes only
+      const double y = __shfl_down(Inc[i], 1, 64);
+      o.E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
+      o.I0[i] = bcast0(Inc[i]);  // lane 0's inclusive product carries the rows across the tile
+    }
+  };
+  auto stage2 = [&](const Scan& sc, const Raw& r) {
+    double Ls[RM * X], jr[RM * V];
+#pragma unroll URM
+    for (int i = 0; i < RM; ++i) {
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        double tt2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt2 += Lam[i * X + a] * sc.E[a * X + d];
+        Ls[i * X + d] = tt2;
+      }
+#pragma unroll
+      for (int d = 0; d < V; ++d) {
+        double tt2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * sc.Bm[a * V + d];
+        jr[i * V + d] = tt2;
+      }
+#pragma unroll
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt2 = zacc[i * Z + mz];
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * sc.Zf[a * Z + mz];
+        zacc[i * Z + mz] = tt2;
+      }
+    }
+    const size_t col = colb + (size_t)r.s * V;
+    if (MODE == 0) {
+      if (r.valid) {
+#pragma unroll URM
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int d = 0; d < V; ++d) Jo[(size_t)i * NV + col + d] = jr[i * V + d];
+      }
+#pragma unroll URM
+      for (int i = 0; i < RM; ++i)
+#pragma unroll URM
+        for (int jj = 0; jj <= i; ++jj) {
+          double tt2 = Dacc[i * RM + jj];
+#pragma unroll
+          for (int d = 0; d < V; ++d) tt2 += jr[i * V + d] * jr[jj * V + d];
+          Dacc[i * RM + jj] = tt2;
+        }
+    } else {
+#pragma unroll URM
+      for (int i = 0; i < RM; ++i)
+#pragma unroll URM
+        for (int jj = 0; jj < RM; ++jj) {
+          double tt2 = Dacc[i * RM + jj];
+#pragma unroll
+          for (int d = 0; d < V; ++d) tt2 += jr[i * V + d] * r.jp[jj * V + d];
+          Dacc[i * RM + jj] = tt2;
+        }
+    }
+    // carry the adjoint rows to the start of this tile: Lam <- Lam Inc_0
+#pragma unroll URM
+    for (int i = 0; i < RM; ++i) {
+      double nl[X];
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        double tt2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt2 += Lam[i * X + a] * sc.I0[a * X + d];
+        nl[d] = tt2;
+      }
+#pragma unroll
+      for (int d = 0; d < X; ++d) Lam[i * X + d] = nl[d];
+    }
+  };
+  Raw r0, r1, r2;
+  Scan sc0, sc1;
+  fetch(ntot - 1, r0);
+  fetch(ntot - 2, r1);
+  stage1(r0, sc0);
   for (int tt = ntot - 1; tt >= 0; --tt) {
     const int j = tt / ntile, t = tt - j * ntile;
-    double nx[X], nv[V], njp[RM * V];
-    bool nvalid = false;
-    int ns = 0;
-    if (tt > 0) fetch(tt - 1, nx, nv, njp, nvalid, ns);
+    fetch(tt - 2, r2);
     if (t == ntile - 1) {
       // rows that start at the end of observation interval j
       if (j < bd.ny) {
         double g[X];
         M::obs_grad(traj + (size_t)(j + 1) * S * X, g);
-#pragma unroll
+#pragma unroll URM
         for (int i = 0; i < RM; ++i)
           if (i == j)
 #pragma unroll
             for (int a = 0; a < X; ++a) Lam[i * X + a] = g[a];
       }
       if (j == bd.nobs - 1 && !bd.last) {
-#pragma unroll
+#pragma unroll URM
         for (int i = 0; i < RM; ++i)
 #pragma unroll
           for (int a = 0; a < X; ++a)
             if (i == bd.ny + a) Lam[i * X + a] = 1.0;
       }
     }
-    // (specialising the tile on the first structurally non-zero row -- rows i < j vanish in interval j -- was
-    // measured slower: eight unrolled copies of the tile body thrash the instruction cache)
-    rev_tile<M, RM, MODE, 0>(cc, lane, cvalid, cs, cx, cv, cjp, Lam, Dacc, zacc, Jo, colb, NV);
-#pragma unroll
-    for (int a = 0; a < X; ++a) cx[a] = nx[a];
-#pragma unroll
-    for (int a = 0; a < V; ++a) cv[a] = nv[a];
-    if (MODE == 1) {
-#pragma unroll
-      for (int i = 0; i < RM * V; ++i) cjp[i] = njp[i];
-    }
-    cvalid = nvalid;
-    cs = ns;
+    stage1(r1, sc1);  // tile tt - 1 (identity when there is none)
+    stage2(sc0, r0);  // tile tt
+    r0 = r1;
+    r1 = r2;
+    sc0 = sc1;
   }
   // x_0 = generate_x_0(z, v_0): the v_0 columns and the z-dependence of the first block (lane 0's share)
   if (bd.first && lane == 0) {
@@ -301,7 +292,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     Dacc[i] = v;
   }
-#pragma unroll
+#pragma unroll URM
   for (int i = 0; i < RM * Z; ++i) {
     double v = zacc[i];
 #pragma unroll
@@ -310,13 +301,13 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   }
   if (lane == 0) {
     if (MODE == 0) {
-#pragma unroll
+#pragma unroll URM
       for (int i = 0; i < RM; ++i)
-#pragma unroll
+#pragma unroll URM
         for (int jj = 0; jj < i; ++jj) Dacc[jj * RM + i] = Dacc[i * RM + jj];
     }
     const double s2 = sy.sigma * sy.sigma;
-#pragma unroll
+#pragma unroll URM
     for (int i = 0; i < RM; ++i) {
       if (sy.noisy && i < bd.ny) Dacc[i * RM + i] += s2;  // dc/dn dc/dn^T (:772-791)
       if (i >= bd.nrows) Dacc[i * RM + i] = 1.0;          // identity padding
@@ -326,7 +317,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
     for (int i = 0; i < RM * RM; ++i) Do[i] = Dacc[i];
     if (MODE == 0) {
       double* zo = w.zbP + cb * RM * Z;
-#pragma unroll
+#pragma unroll URM
       for (int i = 0; i < RM * Z; ++i) zo[i] = zacc[i];
     }
     double G[Z * Z];
