@@ -99,7 +99,7 @@ def main():
 
     # ---- untimed burn-in: the linear-interpolation initial states are far from the typical set
     for _ in range(a.burn_iters):
-        wl.refresh_momentum_device(torch, dev)
+        wl.refresh_momentum()
         act = np.ones(B, dtype=np.int32)
         for _ in range(a.burn_steps):
             r = wl.step(a.burn_step_size, active=act)
@@ -112,7 +112,7 @@ def main():
             if k % a.traj_len == 0:  # IndependentMomentumTransition + SwitchPartitionTransition between trajectories
                 if k:
                     ctx.switch_partition()
-                wl.refresh_momentum_device(torch, dev)
+                wl.refresh_momentum()  # device-side Philox stream + projection
             r = wl.step(a.step_size)
             k += 1
             if stats is not None:

@@ -71,6 +71,10 @@ int chmc_get_state(chmc_ctx* ctx, double* q, double* p, double* x_obs_seq, int* 
 int chmc_set_momentum(chmc_ctx* ctx, const double* p);
 int chmc_get_state_device(chmc_ctx* ctx, void* q_dev, void* p_dev);  /* device-to-device copies */
 int chmc_set_momentum_device(chmc_ctx* ctx, const void* p_dev);
+/* system.sample_momentum(state, rng) (:1256-1259) with a device-side counter-based generator: mom = P(q) n,
+ * n ~ N(0, I) from Philox4x32-10 keyed by `seed`, counter (component pair, `draw`, chain_offset + chain): the
+ * stream of a chain does not depend on how chains are sharded over GPUs. */
+int chmc_sample_momentum(chmc_ctx* ctx, unsigned long long seed, unsigned long long draw, int chain_offset);
 /* system.update_x_obs_seq(state) (:1240-1241, :384-397) */
 int chmc_update_x_obs_seq(chmc_ctx* ctx);
 /* SwitchPartitionTransition.sample (:1279-1282): partition = (partition + 1) % num_partition, update x_obs_seq,

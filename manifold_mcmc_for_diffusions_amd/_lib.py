@@ -38,6 +38,7 @@ SYMBOLS = [
     ("chmc_set_momentum", C.c_int, [C.c_void_p, dp]),
     ("chmc_get_state_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("chmc_set_momentum_device", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("chmc_sample_momentum", C.c_int, [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int]),
     ("chmc_update_x_obs_seq", C.c_int, [C.c_void_p]),
     ("chmc_switch_partition", C.c_int, [C.c_void_p]),
     ("chmc_constr", C.c_int, [C.c_void_p, dp]),

@@ -91,6 +91,10 @@ class ChmcContext:
     def set_momentum_device(self, p_dev_ptr):
         check(self.L.chmc_set_momentum_device(self.h, C.c_void_p(p_dev_ptr)), "chmc_set_momentum_device")
 
+    def sample_momentum(self, seed, draw, chain_offset=0):
+        """Momentum refresh on the device: N(0, I) from a counter-based generator, projected onto the cotangent space."""
+        check(self.L.chmc_sample_momentum(self.h, int(seed), int(draw), int(chain_offset)), "chmc_sample_momentum")
+
     def update_x_obs_seq(self):
         check(self.L.chmc_update_x_obs_seq(self.h), "chmc_update_x_obs_seq")
 

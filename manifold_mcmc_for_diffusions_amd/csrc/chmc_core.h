@@ -1328,6 +1328,43 @@ struct KUpdate {
   }
 };
 
+// ------------------------------------------------------------------------------------------
+// Counter-based normal generator for the momentum refresh (IndependentMomentumTransition -> sample_momentum,
+// :1256-1259): Philox4x32-10 (Salmon et al. 2011) keyed by the seed, counter = (component pair, draw index,
+// global chain id), two 53-bit uniforms -> Box-Muller.  Stateless, so any sharding of the chains over GPUs and
+// any launch geometry produce the same stream; tests/test_rng.py restates it in NumPy.
+CHMC_HD inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                  uint32_t* out) {
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+  }
+  out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+struct KNormalFill {  // one work item per (chain, component pair); writes N(0, 1) into the state slot's momentum
+  Sys sy;
+  Slots sl;
+  unsigned long long seed, draw;
+  int chain_offset;
+  CHMC_HD void operator()(int tid) const {
+    const int npair = (sy.Q + 1) / 2;
+    const int c = tid / npair, j = tid - c * npair;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)j, (uint32_t)draw, (uint32_t)(c + chain_offset), (uint32_t)(draw >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    const double u1 = (((uint64_t)r[0] << 21) ^ ((uint64_t)r[1] >> 11)) * (1.0 / 9007199254740992.0) +
+                      (0.5 / 9007199254740992.0);  // (0, 1)
+    const double u2 = (((uint64_t)r[2] << 21) ^ ((uint64_t)r[3] >> 11)) * (1.0 / 9007199254740992.0);
+    const double rad = sqrt(-2.0 * log(u1)), ang = 6.283185307179586476925286766559 * u2;
+    double* p = pick(sl.p, sl.cur[c]) + (size_t)c * sy.Q;
+    p[2 * j] = rad * cos(ang);
+    if (2 * j + 1 < sy.Q) p[2 * j + 1] = rad * sin(ang);
+  }
+};
+
 // lax.while_loop condition (:1119-1127) evaluated per chain after each iteration, and the status mapping of
 // the host wrappers (:1462-1476): 0 converged, 1 did not converge, 2 diverged / NaN.
 struct KCheck {

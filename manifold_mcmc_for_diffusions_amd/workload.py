@@ -18,6 +18,7 @@ class FhnWorkload:
                  num_steps_per_obs_data=10000, seed=SEED):
         self.B, self.S, self.T, self.R = num_chains, num_steps_per_obs, num_obs, num_obs_per_subseq
         self.sigma, self.obs_interval = sigma, obs_interval
+        self.seed, self.chain_offset = seed, chain_offset
         self.y = em.simulate_fhn_observations(num_obs, obs_interval, num_steps_per_obs_data, seed=seed, sigma=sigma)
         self.ctx = ChmcContext("fhn", obs_interval, num_steps_per_obs, num_obs_per_subseq, self.y[:, 0], sigma=sigma,
                                use_gaussian_splitting=use_gaussian_splitting, num_chains=num_chains, device=device)
@@ -45,6 +46,11 @@ class FhnWorkload:
         torch.cuda.synchronize(device)
         self.ctx.set_momentum_device(self._pbuf.data_ptr())
         self.ctx.project_onto_cotangent_space()
+
+    def refresh_momentum(self):
+        """Device-side refresh (Philox stream keyed by the workload seed; draw counter per call)."""
+        self._draw = getattr(self, "_draw", 0) + 1
+        self.ctx.sample_momentum(self.seed, self._draw, self.chain_offset)
 
     def step(self, dt, active=None):
         return self.ctx.leapfrog_step(dt, active=active, **self.solver)
