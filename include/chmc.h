@@ -75,6 +75,13 @@ int chmc_set_momentum_device(chmc_ctx* ctx, const void* p_dev);
  * n ~ N(0, I) from Philox4x32-10 keyed by `seed`, counter (component pair, `draw`, chain_offset + chain): the
  * stream of a chain does not depend on how chains are sharded over GPUs. */
 int chmc_sample_momentum(chmc_ctx* ctx, unsigned long long seed, unsigned long long draw, int chain_offset);
+/* Caller support for an accept / reject step around a trajectory (the role of Mici's transitions, which keep the
+ * start state and discard a rejected or failed trajectory): device-side copy of (pos, mom) and masked restore
+ * (mask [B], non-zero = restore; the state caches of restored chains are re-evaluated).  chmc_get_head copies the
+ * first n components of every chain's position ([B][n]: u and v_0 live there, cf. trace_func of the scripts). */
+int chmc_snapshot(chmc_ctx* ctx);
+int chmc_restore(chmc_ctx* ctx, const int* mask);
+int chmc_get_head(chmc_ctx* ctx, int n, double* out);
 /* system.update_x_obs_seq(state) (:1240-1241, :384-397) */
 int chmc_update_x_obs_seq(chmc_ctx* ctx);
 /* SwitchPartitionTransition.sample (:1279-1282): partition = (partition + 1) % num_partition, update x_obs_seq,

@@ -39,6 +39,9 @@ SYMBOLS = [
     ("chmc_get_state_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("chmc_set_momentum_device", C.c_int, [C.c_void_p, C.c_void_p]),
     ("chmc_sample_momentum", C.c_int, [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int]),
+    ("chmc_snapshot", C.c_int, [C.c_void_p]),
+    ("chmc_restore", C.c_int, [C.c_void_p, ip]),
+    ("chmc_get_head", C.c_int, [C.c_void_p, C.c_int, dp]),
     ("chmc_update_x_obs_seq", C.c_int, [C.c_void_p]),
     ("chmc_switch_partition", C.c_int, [C.c_void_p]),
     ("chmc_constr", C.c_int, [C.c_void_p, dp]),

@@ -95,6 +95,18 @@ class ChmcContext:
         """Momentum refresh on the device: N(0, I) from a counter-based generator, projected onto the cotangent space."""
         check(self.L.chmc_sample_momentum(self.h, int(seed), int(draw), int(chain_offset)), "chmc_sample_momentum")
 
+    def snapshot(self):
+        check(self.L.chmc_snapshot(self.h), "chmc_snapshot")
+
+    def restore(self, mask):
+        m = np.ascontiguousarray(mask, dtype=np.int32)
+        check(self.L.chmc_restore(self.h, iptr(m)), "chmc_restore")
+
+    def get_head(self, n):
+        out = np.empty((self.B, n))
+        check(self.L.chmc_get_head(self.h, int(n), ptr(out)), "chmc_get_head")
+        return out
+
     def update_x_obs_seq(self):
         check(self.L.chmc_update_x_obs_seq(self.h), "chmc_update_x_obs_seq")
 

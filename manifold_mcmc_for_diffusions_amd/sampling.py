@@ -1,0 +1,70 @@
+"""A minimal batched sampler on top of the device step: static-length constrained HMC trajectories with a Metropolis
+accept step, momentum refresh, partition switching and dual-averaging step-size adaptation.
+
+The reference drives the same integrator with Mici's dynamic multinomial (NUTS-style) transition
+(scripts/utils.py:292-306); that transition is a caller of the hot path and out of this round's scope (SURVEY.md
+8f #2).  This static variant targets the same posterior (it is a valid Markov kernel for it) and exists to exercise
+the path end to end: momentum -> L constrained leapfrog steps -> accept / reject -> SwitchPartitionTransition."""
+import numpy as np
+
+
+class DualAveragingStepSize:
+    """Hoffman & Gelman dual averaging on the mean accept statistic (cf. mici DualAveragingStepSizeAdapter,
+    scripts/utils.py:303-306), one step size shared by all chains."""
+
+    def __init__(self, step_size, target=0.8, gamma=0.05, t0=10.0, kappa=0.75):
+        self.mu = np.log(10 * step_size)
+        self.target, self.gamma, self.t0, self.kappa = target, gamma, t0, kappa
+        self.h_bar, self.log_bar, self.t = 0.0, np.log(step_size), 0
+        self.step_size = step_size
+
+    def update(self, accept_stat):
+        self.t += 1
+        eta = 1.0 / (self.t + self.t0)
+        self.h_bar = (1 - eta) * self.h_bar + eta * (self.target - accept_stat)
+        log_eps = self.mu - np.sqrt(self.t) / self.gamma * self.h_bar
+        w = self.t ** (-self.kappa)
+        self.log_bar = w * log_eps + (1 - w) * self.log_bar
+        self.step_size = float(np.exp(log_eps))
+        return self.step_size
+
+    def final(self):
+        return float(np.exp(self.log_bar))
+
+
+def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_adapt=0, solver=None, rng=None,
+                       n_head=6, callback=None):
+    """Runs n_iter transitions on all chains of `ctx`; returns traces of the first `n_head` position components
+    ([n_iter, B, n_head]), accept statistics and the step size used.  Directions are sampled per chain and
+    transition (forward / backward in time), failed trajectories are rejected."""
+    solver = dict(newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10, max_iters=50,
+                  reverse_check_tol=2e-8) if solver is None else solver
+    rng = np.random.default_rng(seed) if rng is None else rng
+    adapter = DualAveragingStepSize(step_size) if n_adapt > 0 else None
+    B = ctx.B
+    heads = np.empty((n_iter, B, n_head))
+    acc_hist, eps_hist, fail_hist = np.empty(n_iter), np.empty(n_iter), np.empty(n_iter)
+    for it in range(n_iter):
+        ctx.sample_momentum(seed, it + 1, chain_offset)
+        h0 = ctx.hamiltonian()[:, 0]
+        ctx.snapshot()
+        dt = np.where(rng.random(B) < 0.5, step_size, -step_size)
+        act = np.ones(B, dtype=np.int32)
+        for _ in range(n_step):
+            r = ctx.leapfrog_step(dt, active=act, **solver)
+            act &= (r["status"] == 0).astype(np.int32)
+        h1 = ctx.hamiltonian()[:, 0]
+        dh = h1 - h0
+        prob = np.where((act == 1) & np.isfinite(dh), np.exp(np.minimum(0.0, -np.where(np.isfinite(dh), dh, np.inf))), 0.0)
+        accept = rng.random(B) < prob
+        ctx.restore((~accept).astype(np.int32))
+        ctx.switch_partition()
+        heads[it] = ctx.get_head(n_head)
+        acc_hist[it], eps_hist[it], fail_hist[it] = prob.mean(), step_size, 1.0 - act.mean()
+        if adapter is not None and it < n_adapt:
+            step_size = adapter.update(prob.mean())
+            if it == n_adapt - 1:
+                step_size = adapter.final()
+        if callback is not None:
+            callback(it, heads[it], prob.mean(), step_size)
+    return dict(heads=heads, accept_stat=acc_hist, step_size=eps_hist, fail_rate=fail_hist, final_step_size=step_size)
