@@ -967,4 +967,12 @@ __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work
 // plain lane-per-block scan of chmc_core.h: with one wavefront per SIMD the extra LDS round trips sit on the
 // critical path of the sequential recursion.  It was removed.)
 
+// (A blocked variant of k_rev_wave -- every lane owning 4 consecutive steps, composing their transition matrices
+// locally so that only lane aggregates go through the shuffle scan, and multiplying the carried rows into per-lane
+// sums once per 256-step tile -- was built, passed the parity suite and cut vector instructions per block by 28 %
+// (SQ_INSTS_VALU 14.4 k vs 20 k per wavefront at N4).  It still ran 10-25 % slower (newton_blk 3.55 vs 3.21 ms per
+// step, state_blk 0.54 vs 0.43): at 256 VGPR + 248 AGPR it has no registers left for the two-stage prefetch of
+// k_rev_wave, so with one wavefront per SIMD the 64-byte-strided loads sit exposed (SQ_WAIT_INST_ANY > busy
+// cycles).  It was removed.)
+
 }  // namespace chmc
