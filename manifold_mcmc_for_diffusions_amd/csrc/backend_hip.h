@@ -188,6 +188,24 @@ static void launch_wave(K kern, long nwaves, int cls, Args... args) {
     if (g_prof_pending.size() > 4096) prof_drain();
   }
 }
+// explicit grid / block launch (forward-scan kernel: one or two wavefronts per workgroup)
+template <class K, class... Args>
+static void launch_blocks(K kern, long nblocks, int bs, int cls, Args... args) {
+  if (nblocks <= 0) return;
+  ProfRec r;
+  const bool prof = g_prof_on_for(cls);
+  if (prof) {
+    r.a = prof_event(), r.b = prof_event(), r.cls = cls;
+    note(hipEventRecord(r.a, g_stream));
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(bs), 0, g_stream, args...);
+  note(hipGetLastError());
+  if (prof) {
+    note(hipEventRecord(r.b, g_stream));
+    g_prof_pending.push_back(r);
+    if (g_prof_pending.size() > 4096) prof_drain();
+  }
+}
 extern "C" int chmc_profile_enable(int on) {
   if (g_stream) prof_drain();
   for (int i = 0; i < 16; ++i) g_prof_ms[i] = 0.0, g_prof_n[i] = 0;

@@ -31,7 +31,10 @@
 
 namespace chmc {
 
-#define CHMC_Q_PAD 64  // doubles of slack after every [B][Q] position buffer (see fwd_block)
+#ifndef CHMC_FWD_DEPTH
+#define CHMC_FWD_DEPTH 4  // tiles of noise increments in flight in the forward scans
+#endif
+#define CHMC_Q_PAD 256 // doubles of slack after every [B][Q] position buffer (see fwd_block)
 
 struct BlockDesc {
   int obs0, nobs, first, last;
@@ -574,6 +577,40 @@ struct KXobs {
     const double* v = q + sy.U + sy.V0;
     double* out = xobs_out + (size_t)c * sy.T * X;
     const int L = sy.T * sy.S;
+    if (sy.S % PF == 0) {  // same ring of in-flight tiles as fwd_block_impl
+      constexpr int DEPTH = CHMC_FWD_DEPTH;
+      double ring[DEPTH][PF * V];
+      CHMC_UNROLL
+      for (int d = 0; d < DEPTH; ++d) {
+        CHMC_UNROLL
+        for (int i = 0; i < PF * V; ++i) ring[d][i] = v[d * PF * V + i];
+      }
+      int left = sy.S, t = 0;
+      for (int s0 = 0; s0 < L; s0 += PF * DEPTH) {
+        CHMC_UNROLL
+        for (int d = 0; d < DEPTH; ++d) {
+          const int s = s0 + d * PF;
+          if (s < L) {
+            CHMC_UNROLL
+            for (int i = 0; i < PF; ++i) {
+              M::step(cc.k, x, ring[d] + i * V, xn);
+              CHMC_UNROLL
+              for (int a = 0; a < X; ++a) x[a] = xn[a];
+            }
+            const double* vn = v + (size_t)(s + PF * DEPTH) * V;
+            CHMC_UNROLL
+            for (int i = 0; i < PF * V; ++i) ring[d][i] = vn[i];
+            left -= PF;
+            if (left == 0) {
+              for (int a = 0; a < X; ++a) out[t * X + a] = x[a];
+              ++t;
+              left = sy.S;
+            }
+          }
+        }
+      }
+      return;
+    }
     double cur[PF * V], nxt[PF * V];
     CHMC_UNROLL
     for (int i = 0; i < PF * V; ++i) cur[i] = v[i];
@@ -1237,6 +1274,17 @@ struct KSolveChain {
 struct double2_ {
   double x, y;
 };
+// streaming 16-byte load (Jacobian rows are read once per sweep: keep them out of the caches' way)
+CHMC_HD inline double2_ ld2_stream(const double* p) {
+  double2_ r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  r.x = __builtin_nontemporal_load(p);
+  r.y = __builtin_nontemporal_load(p + 1);
+#else
+  r.x = p[0], r.y = p[1];
+#endif
+  return r;
+}
 template <int RM, int TGT, int VEC>
 struct KUpdate {
   Sys sy;
@@ -1290,7 +1338,7 @@ struct KUpdate {
       for (int i = 0; i < RM; ++i) {
         if (i >= m && i < nr) {
           if (VEC == 2) {
-            const double2_ jv = *reinterpret_cast<const double2_*>(Jv + (size_t)i * sy.NV);
+            const double2_ jv = ld2_stream(Jv + (size_t)i * sy.NV);
             d[0] += jv.x * lam[i];
             d[VEC - 1] += jv.y * lam[i];
           } else {

@@ -18,6 +18,12 @@
 
 namespace chmc {
 
+// Trajectories are streamed: written once by the forward scan (non-temporal stores) and read once per sweep.  A
+// plain read leaves the lines allocated in L2 / Infinity Cache and the next scan's streaming stores to the same
+// addresses then run at half speed (tools/ubench/fwd_latency.hip: 107 us vs 187 us per scan), so the readers use
+// the non-temporal hint as well.
+__device__ inline double ld_stream(const double* p) { return __builtin_nontemporal_load(p); }
+
 __device__ inline double bcast0(double x) {  // value of lane 0, as a wave-uniform value
   union { double d; int i[2]; } u;
   u.d = x;
@@ -97,7 +103,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
     r.s = jj * S + off;
     if (r.valid) {
 #pragma unroll
-      for (int a = 0; a < X; ++a) r.x[a] = traj[(size_t)r.s * X + a];
+      for (int a = 0; a < X; ++a) r.x[a] = ld_stream(traj + (size_t)r.s * X + a);
 #pragma unroll
       for (int a = 0; a < V; ++a) r.v[a] = vbase[(size_t)r.s * V + a];
       if (MODE == 1) {
@@ -105,7 +111,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
 #pragma unroll URM
         for (int i = 0; i < RM; ++i)  // (skipping the structurally zero rows here breaks the load pipelining: 2x slower)
 #pragma unroll
-          for (int d = 0; d < V; ++d) r.jp[i * V + d] = Jr[(size_t)i * NV + col + d];
+          for (int d = 0; d < V; ++d) r.jp[i * V + d] = ld_stream(Jr + (size_t)i * NV + col + d);
       }
     } else {
 #pragma unroll
@@ -454,7 +460,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
         if (valid) {
           double x[X], vv[V];
 #pragma unroll
-          for (int a = 0; a < X; ++a) x[a] = traj[(size_t)s * X + a];
+          for (int a = 0; a < X; ++a) x[a] = ld_stream(traj + (size_t)s * X + a);
 #pragma unroll
           for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
           M::jac(cc.k, x, vv, A, Bm, Zf);
@@ -654,7 +660,7 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
       double A[X * X], Bm[X * V], Zf[X * Z], x[X], vv[V];
       if (valid) {
 #pragma unroll
-        for (int a = 0; a < X; ++a) x[a] = traj[(size_t)s * X + a];
+        for (int a = 0; a < X; ++a) x[a] = ld_stream(traj + (size_t)s * X + a);
 #pragma unroll
         for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
         M::jac(cc.k, x, vv, A, Bm, Zf);
@@ -960,6 +966,239 @@ __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work
       for (int a = 0; a < U; ++a) p[a] -= du[a];
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward scan of `constr` (:473-519) for S % 8 == 0: lane l of a wavefront integrates block (chain, block) =
+// tid of the launch, exactly like fwd_block_impl, but with the memory traffic arranged by hand.  The recursion is
+// latency bound (one wavefront per SIMD issues ~14 dependent fp64 instructions per step, 2.7 ns each), so every
+// cycle the wave spends on memory instructions or waiting for them is lost (tools/ubench/fwd_latency.hip):
+//   * loads: each lane walks its own 128-byte lines of noise increments.  hipcc drains the whole vector-memory
+//     queue (s_waitcnt vmcnt(0)) at the first use of a loaded tile, which exposes a full HBM round trip per tile;
+//     here the loads are issued through inline asm into a ring of DEPTH tiles and waited for with a counted
+//     s_waitcnt (loads retire in issue order, MI355X_MICROARCH.md), which hides them completely;
+//   * stores: a lane-per-block store instruction writes 16 bytes to 64 different lines (~95 ns of issue per
+//     instruction).  The integrating wave only parks its 8-step trajectory tile in LDS; a second, helper wavefront
+//     of the workgroup reads the tile back transposed (8 lanes per 128-byte row) and issues the global stores, so
+//     that stores cost the integrating wave nothing and never sit in its vmcnt queue.
+// The two waves meet at one s_barrier per tile (the integrating wave signals tile t when it starts tile t+1); the
+// tile buffers alternate.
+typedef double d2_t __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ void vm_load16(d2_t& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(p), "n"(OFF) : "memory");
+}
+template <int I, int N, int OFF0>
+struct TileLoad {
+  static __device__ __forceinline__ void run(d2_t* r, const void* p) {
+    vm_load16<OFF0 + 16 * I>(r[I], p);
+    TileLoad<I + 1, N, OFF0>::run(r, p);
+  }
+};
+template <int N, int OFF0>
+struct TileLoad<N, N, OFF0> {
+  static __device__ __forceinline__ void run(d2_t*, const void*) {}
+};
+// wait until at most NOUT vector-memory operations are outstanding; the tile's registers are tied to the wait so
+// that no use of them can be scheduled above it
+template <int NOUT>
+__device__ __forceinline__ void vm_wait(d2_t (&r)[8]) {
+  asm volatile("s_waitcnt vmcnt(%8)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+               : "n"(NOUT)
+               : "memory");
+}
+template <int NOUT>
+__device__ __forceinline__ void vm_wait(d2_t (&r)[12]) {
+  asm volatile("s_waitcnt vmcnt(%12)"
+               : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]),
+                 "+v"(r[8]), "+v"(r[9]), "+v"(r[10]), "+v"(r[11])
+               : "n"(NOUT)
+               : "memory");
+}
+// streaming store: the trajectory is written once and read back by other workgroups much later; without the
+// non-temporal hint every new line is allocated in L2 and the per-CU write path (not HBM) paces the helper wave
+// (tools/ubench/fwd_latency.hip: 70 -> 49 ns per step)
+__device__ __forceinline__ void vm_store16_nt(double* p, const d2_t& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <class M, int RM, bool STORE>
+__global__ void __launch_bounds__(STORE ? 128 : 64)
+    k_fwd_scan(Sys sy, Slots sl, Work w, int which, int qsel, int use_nw, int store_traj) {
+  constexpr int X = M::X, V = M::V, PF = 8;
+  constexpr int NLD = PF * V / 2;        // 16-byte loads per lane and tile
+  constexpr int NST = PF * X / 2;        // 16-byte chunks per trajectory row and tile
+  constexpr int TBV = PF * V * 8;        // bytes of noise increments per tile
+  constexpr int DEPTH = V == 2 ? 4 : 3;  // tiles in flight
+  constexpr int NOUT = (DEPTH - 1) * NLD;
+  constexpr int RSD = PF * X + 2;        // LDS row stride in doubles: tile + 16 bytes (conflict-free row access)
+  static_assert(NOUT <= 63, "vmcnt is a 6-bit field");
+  __shared__ __attribute__((aligned(16))) double tile[STORE ? 2 : 1][STORE ? 64 * RSD : 2];
+  __shared__ double obsv[64 * (2 * RM + 1)];
+  const int lane = threadIdx.x & 63;
+  const bool helper = STORE && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) != 0;
+  const int n = sy.B * sy.K, S = sy.S;
+  const int tid0 = blockIdx.x * 64;
+
+  // both waves work out the longest block of the 64 (same loop trip count and barrier count)
+  int maxL = 0;
+  {
+    const int t = tid0 + lane;
+    int L = 0;
+    if (t < n) {
+      const int c = t / sy.K;
+      if (use_nw ? w.nw[c] != 0 : w.ok[c] != 0) L = sy.blk[t - c * sy.K].nsteps;
+    }
+    maxL = L;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int o = __shfl_xor(maxL, off, 64);
+      maxL = o > maxL ? o : maxL;
+    }
+    maxL = __builtin_amdgcn_readfirstlane(maxL);
+  }
+  if (maxL == 0) return;
+
+  if (helper) {
+    // rows of this lane: chunk g = 64 i + lane of the 64 x NST chunks of a tile -> row g / NST, chunk g % NST
+    double* rp[NST];
+    int rL[NST], lo_[NST];
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+      const int g = 64 * i + lane, r = g / NST, ch = g - r * NST;
+      const int t = tid0 + r;
+      rp[i] = w.trajw, rL[i] = 0, lo_[i] = r * RSD + 2 * ch;  // (a global pointer: no generic-address stores)
+      if (t < n) {
+        const int c = t / sy.K, b = t - c * sy.K;
+        if (use_nw ? w.nw[c] != 0 : w.ok[c] != 0) {
+          const BlockDesc bd = sy.blk[b];
+          const int s = sl.cur[c] ^ which;
+          rp[i] = (store_traj == 2 ? w.trajw : pick(sl.traj, s)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X + 2 * ch;
+          rL[i] = bd.nsteps;
+        }
+      }
+    }
+    int buf = 0;
+    for (int st = 0; st < maxL; st += PF) {
+      lds_barrier();  // tile `st` is in tile[buf]
+      d2_t tt[NST];
+#pragma unroll
+      for (int i = 0; i < NST; ++i) tt[i] = *reinterpret_cast<const d2_t*>(&tile[buf][lo_[i]]);
+#pragma unroll
+      for (int i = 0; i < NST; ++i)
+        if (st < rL[i]) vm_store16_nt(rp[i] + (size_t)st * X, tt[i]);
+      buf ^= 1;
+    }
+    return;
+  }
+
+  // ---- integrating wave
+  const int tid = tid0 + lane;
+  const int tc = tid < n ? tid : n - 1;  // lanes past the end shadow the last block (valid addresses, no output)
+  const int c = tc / sy.K, b = tc - c * sy.K;
+  const BlockDesc bd = sy.blk[b];
+  const bool act = tid < n && (use_nw ? w.nw[c] != 0 : w.ok[c] != 0);
+  const int L = act ? bd.nsteps : 0;
+  const int s = sl.cur[c] ^ which;
+  const double* q = (qsel ? w.qb : pick(sl.q, s)) + (size_t)c * sy.Q;
+  const double* xobs = sy.xobs + (size_t)c * sy.T * X;
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  double x[X], xn[X];
+  const double* vb = q + sy.U;
+  if (bd.first) {
+    M::gx0(cc.z, vb, x);
+  } else {
+#pragma unroll
+    for (int a = 0; a < X; ++a) x[a] = xobs[(bd.obs0 - 1) * X + a];
+  }
+  // observation targets of this block, parked in LDS (a global load inside the loop would make hipcc drain the ring)
+  double* ov = obsv + lane * (2 * RM + 1);
+  {
+    const double* nn = q + sy.U + sy.NV;
+    for (int j = 0; j < bd.ny; ++j) {
+      ov[2 * j] = sy.y[bd.obs0 + j];
+      ov[2 * j + 1] = sy.noisy ? nn[bd.obs0 + j] : 0.0;
+    }
+  }
+  double cp[RM];
+#pragma unroll
+  for (int i = 0; i < RM; ++i) cp[i] = 0.0;
+
+  const char* vp = reinterpret_cast<const char*>(vb + sy.V0 + (size_t)bd.step0 * V);
+  d2_t ring[DEPTH][NLD];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) TileLoad<0, NLD, 0>::run(ring[d], vp + d * TBV);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) vm_wait<0>(ring[d]);  // prologue tiles: simply drain, once per scan
+
+  int left = S, j = 0;  // wave-uniform: every block starts at an observation time
+  for (int s0 = 0; s0 < maxL; s0 += PF * DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int st = s0 + d * PF;
+      if (st < maxL) {
+        // ring[d] was refilled DEPTH tiles ago; DEPTH - 1 younger tiles may stay in flight
+        vm_wait<NOUT>(ring[d]);
+        // hand the previous tile to the helper: its LDS writes were issued at least one step ago, so the wait is free
+        if (STORE && st > 0) lds_barrier();
+        if (st < L) {
+          double* lo = STORE ? &tile[(st >> 3) & 1][lane * RSD] : nullptr;
+#pragma unroll
+          for (int i = 0; i < PF; ++i) {
+            double vt[V];
+#pragma unroll
+            for (int a = 0; a < V; ++a) vt[a] = ring[d][(i * V + a) >> 1][(i * V + a) & 1];
+            if (STORE) {
+#pragma unroll
+              for (int a = 0; a < X; ++a) lo[i * X + a] = x[a];
+            }
+            M::step(cc.k, x, vt, xn);
+#pragma unroll
+            for (int a = 0; a < X; ++a) x[a] = xn[a];
+          }
+        }
+        // refill with the tile DEPTH ahead; a finished lane keeps re-reading its last tiles (never consumed; the
+        // position buffers carry CHMC_Q_PAD doubles of slack for the over-read at the end of a block)
+        TileLoad<0, NLD, DEPTH * TBV>::run(ring[d], vp);
+        if (st < L) vp += TBV;
+        left -= PF;
+        if (left == 0) {  // st + PF is the time of local observation j
+          if (st < L && j < bd.ny) {
+            const double val = (M::obs(x) + (sy.noisy ? sy.sigma * ov[2 * j + 1] : 0.0)) - ov[2 * j];
+#pragma unroll
+            for (int jj = 0; jj < RM; ++jj)
+              if (jj == j) cp[jj] = val;
+          }
+          ++j;
+          left = S;
+        }
+      }
+    }
+  }
+  if (STORE) lds_barrier();  // last tile
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) vm_wait<0>(ring[d]);  // nothing may land in a register after this point
+  if (!act) return;
+  if (STORE) {
+    double* trow = (store_traj == 2 ? w.trajw : pick(sl.traj, s)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+#pragma unroll
+    for (int a = 0; a < X; ++a) trow[(size_t)L * X + a] = x[a];
+  }
+  if (!bd.last) {
+#pragma unroll
+    for (int a = 0; a < X; ++a) {
+      const double val = x[a] - xobs[(bd.obs0 + bd.nobs - 1) * X + a];
+#pragma unroll
+      for (int jj = 0; jj < RM; ++jj)
+        if (jj == bd.ny + a) cp[jj] = val;
+    }
+  }
+  double* out = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
+#pragma unroll
+  for (int i = 0; i < RM; ++i) out[i] = cp[i];
 }
 
 // (An LDS-staged variant of the forward scan -- 8 lanes fetching one block's 128-byte tile, tiles parked in LDS with a
