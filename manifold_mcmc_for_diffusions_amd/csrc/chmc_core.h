@@ -79,7 +79,7 @@ struct Work {
   double* Ew;       // [B][Kmax][RM][U] D_b^-1 dc/du (current iterate)
   double* Cb;       // [B][Kmax][U][U]
   double* sb;       // [B][Kmax][U]
-  double* mu;       // [B][Q]
+  double* mu;       // [B][Q]        staging for the multiplier output of chmc_project
   double* qb;       // [B][Q]        reverse-check iterate
   double* pb;       // [B][Q]
   double* vin;      // [B][Q]        generic input vector (per-op API)
@@ -1249,11 +1249,9 @@ struct KSolveChain {
     }
     if (TGT == 0) {
       double* q = (qsel ? w.qb : pick(sl.q, s ^ 1)) + (size_t)c * sy.Q;
-      double* mu = w.mu + (size_t)c * sy.Q;
       unsigned long long nb = 0ULL;
       for (int a = 0; a < U; ++a) {
         q[a] -= du[a];
-        mu[a] += du[a];
         unsigned long long vb = absbits(du[a]);
         if (vb > nb) nb = vb;
       }
@@ -1269,7 +1267,7 @@ struct KSolveChain {
 // Column-parallel part of J^T lambda (rmult_by_jacob_constr :879-913) fused with its consumer; a "column max"
 // kernel: work item (chain c, column group), the returned bit pattern is max-reduced per chain into *red(c)
 // by the launcher (wave shuffle + LDS, one atomic per workgroup -- 2e7 same-address atomics serialise).
-//  TGT 0: q -= d, mu += d, ndq = max |d|     TGT 1: p -= d     TGT 2: out = d (work.pb, all columns incl. u)
+//  TGT 0: q -= d, ndq = max |d|              TGT 1: p -= d     TGT 2: out = d (work.pb, all columns incl. u)
 //  VEC 2: one work item handles two adjacent columns with 16-byte accesses (needs even Q, NV, U, V0, V).
 struct double2_ {
   double x, y;
@@ -1305,7 +1303,7 @@ struct KUpdate {
     const size_t qi = (size_t)c * sy.Q + sy.U + col;
     double* tgt = TGT == 0 ? (qsel ? w.qb : pick(sl.q, s ^ 1))
                            : TGT == 1 ? (psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : pick(sl.p, s ^ 1)) : w.pb;
-    double d[VEC], old[VEC], mu[VEC];
+    double d[VEC], old[VEC];
     // issue the read-modify-write operands together with the Jacobian rows
     if (TGT != 2) {
       if (VEC == 2) {
@@ -1313,14 +1311,6 @@ struct KUpdate {
         old[0] = o.x, old[VEC - 1] = o.y;
       } else {
         old[0] = tgt[qi];
-      }
-    }
-    if (TGT == 0) {
-      if (VEC == 2) {
-        const double2_ o = *reinterpret_cast<const double2_*>(w.mu + qi);
-        mu[0] = o.x, mu[VEC - 1] = o.y;
-      } else {
-        mu[0] = w.mu[qi];
       }
     }
     if (col < sy.NV) {
@@ -1356,7 +1346,6 @@ struct KUpdate {
       if (TGT == 0) {
         const unsigned long long vb = absbits(d[k]);
         r = vb > r ? vb : r;
-        mu[k] += d[k];
       }
       old[k] = TGT == 2 ? d[k] : old[k] - d[k];
     }
@@ -1364,13 +1353,8 @@ struct KUpdate {
       double2_ o;
       o.x = old[0], o.y = old[VEC - 1];
       *reinterpret_cast<double2_*>(tgt + qi) = o;
-      if (TGT == 0) {
-        o.x = mu[0], o.y = mu[VEC - 1];
-        *reinterpret_cast<double2_*>(w.mu + qi) = o;
-      }
     } else {
       tgt[qi] = old[0];
-      if (TGT == 0) w.mu[qi] = mu[0];
     }
     return r;
   }
@@ -1532,7 +1516,10 @@ struct KFlow {
     }
   }
 };
-// momentum correction after a successful projection: p -= dh2_flow_mom_dmom @ (mu / dt) (:1233-1238, :1465)
+// momentum correction after a successful projection: p -= dh2_flow_mom_dmom @ (mu / dt) (:1233-1238, :1465).
+// The accumulated multiplier term mu = sum of the position updates is the distance the retraction moved the
+// iterate, mu = h2_flow(q_prev, p) - q_new, so it is re-formed here from the two positions and the momentum instead
+// of being carried (read + written) through every Newton iteration.
 struct KMomFix {
   Sys sy;
   Slots sl;
@@ -1541,9 +1528,17 @@ struct KMomFix {
   CHMC_HD void operator()(int tid) const {
     const int c = tid / sy.Q;
     if (!w.ok[c]) return;
-    const int s = sl.cur[c] ^ which;
-    const double sc = sy.gaussian ? w.cdt[c] / w.sdt[c] : 1.0 / w.dt[c];
-    pick(sl.p, s)[tid] -= sc * w.mu[tid];
+    const int s = sl.cur[c] ^ which;  // the new point; the flow started from slot s ^ 1 with this slot's momentum
+    const double qp = pick(sl.q, s ^ 1)[tid], qn = pick(sl.q, s)[tid], pn = pick(sl.p, s)[tid];
+    double sc, flow;
+    if (sy.gaussian) {  // q cos + p0 sin with p0 recovered from the rotated momentum: (q + sin p_n) / cos
+      sc = w.cdt[c] / w.sdt[c];
+      flow = (qp + w.sdt[c] * pn) / w.cdt[c];
+    } else {
+      sc = 1.0 / w.dt[c];
+      flow = qp + w.dt[c] * pn;
+    }
+    pick(sl.p, s)[tid] = pn - sc * (flow - qn);
   }
 };
 // reverse check distance max |q_back - q_start| (mici maximum_norm); column-max kernel over all Q components

@@ -949,12 +949,10 @@ __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work
   if (lane == 0) {
     if (TGT == 0) {
       double* q = (qsel ? w.qb : pick(sl.q, s ^ 1)) + (size_t)c * sy.Q;
-      double* mu = w.mu + (size_t)c * sy.Q;
       unsigned long long nb = 0ULL;
 #pragma unroll
       for (int a = 0; a < U; ++a) {
         q[a] -= du[a];
-        mu[a] += du[a];
         const unsigned long long vb = absbits(du[a]);
         nb = vb > nb ? vb : nb;
       }
