@@ -129,6 +129,7 @@ int chmc_get_counters(const chmc_ctx* ctx, long long* out8);
  * 6 jacob_vec (J w), 7 constr (forward scan only), 8 element-wise, 9 sym_blk */
 #define CHMC_NUM_KERNEL_CLASSES 10
 int chmc_profile_enable(int on);  /* 0 stop, 1 all classes, else bit mask (1 << class); resets the accumulators */
+int chmc_profile_stride(int every); /* time every `every`-th launch of a profiled class only (default 1); an event pair costs ~30 us of stream bubbles */
 int chmc_profile_get(double* ms, long long* launches);  /* [CHMC_NUM_KERNEL_CLASSES] each; synchronises */
 
 #ifdef __cplusplus

@@ -61,6 +61,7 @@ SYMBOLS = [
                                      C.c_int, C.c_double, ip, ip, ip, dp]),
     ("chmc_get_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     ("chmc_profile_enable", C.c_int, [C.c_int]),
+    ("chmc_profile_stride", C.c_int, [C.c_int]),
     ("chmc_profile_get", C.c_int, [dp, C.POINTER(C.c_longlong)]),
 ]
 KERNEL_CLASSES = ("other", "newton_blk", "state_blk", "grad_log_det_blk", "update", "solve_chain", "jacob_vec",

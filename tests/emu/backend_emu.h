@@ -13,6 +13,9 @@ static void h2d(void* d, const void* h, size_t bytes) { memcpy(d, h, bytes); }
 static void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
 static void d2d(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
 static int dev_sync() { return 0; }
+static int g_poll_val[2];
+static void poll_begin(int slot, const int* d) { g_poll_val[slot] = *d; }
+static int poll_end(int slot) { return g_poll_val[slot]; }
 template <class F>
 static void launch(F f, long n, int cls = 0) {
   (void)cls;
@@ -33,6 +36,7 @@ static void launch_colmax(F f, int ncol, int B, int cls = 0) {
   }
 }
 extern "C" int chmc_profile_enable(int) { return 0; }
+extern "C" int chmc_profile_stride(int) { return 0; }
 extern "C" int chmc_profile_get(double* ms, long long* n) {
   for (int i = 0; i < 10; ++i) {
     if (ms) ms[i] = 0.0;
