@@ -1509,10 +1509,10 @@ struct KFlow {
     }
     if (dst == 0) {
       pick(sl.q, s ^ 1)[tid] = qn;
-      pick(sl.p, s ^ 1)[tid] = pn;
+      // (standard splitting: the flow leaves the momentum as it is, and it already sits in the destination slot)
+      if (sy.gaussian || !from_p_other) pick(sl.p, s ^ 1)[tid] = pn;
     } else {
-      w.qb[tid] = qn;
-      w.pb[tid] = pn;
+      w.qb[tid] = qn;  // reverse-check flow: only the position is compared (KRevDiff), the momentum is not kept
     }
   }
 };
@@ -1541,16 +1541,28 @@ struct KMomFix {
     pick(sl.p, s)[tid] = pn - sc * (flow - qn);
   }
 };
-// reverse check distance max |q_back - q_start| (mici maximum_norm); column-max kernel over all Q components
+// reverse check distance max |q_back - q_start| (mici maximum_norm); column-max kernel, two components per work item
 struct KRevDiff {
   Sys sy;
   Slots sl;
   Work w;
   CHMC_HD bool active(int c) const { return w.ok[c] != 0; }
   CHMC_HD unsigned long long* red(int c) const { return &w.rev[c]; }
-  CHMC_HD unsigned long long operator()(int c, int col) const {
+  CHMC_HD unsigned long long operator()(int c, int idx) const {
+    const int col = 2 * idx;
     const size_t i = (size_t)c * sy.Q + col;
-    return absbits(w.qb[i] - sl.q[sl.cur[c]][i]);
+    const double* qs = pick(sl.q, sl.cur[c]);
+    if (col + 1 < sy.Q && (sy.Q & 1) == 0) {
+      const double2_ a = *reinterpret_cast<const double2_*>(w.qb + i), b = *reinterpret_cast<const double2_*>(qs + i);
+      const unsigned long long u = absbits(a.x - b.x), v = absbits(a.y - b.y);
+      return u > v ? u : v;
+    }
+    unsigned long long r = absbits(w.qb[i] - qs[i]);
+    if (col + 1 < sy.Q) {
+      const unsigned long long v = absbits(w.qb[i + 1] - qs[i + 1]);
+      r = v > r ? v : r;
+    }
+    return r;
   }
 };
 struct KRevCheck {
