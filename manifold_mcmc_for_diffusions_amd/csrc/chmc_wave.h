@@ -14,6 +14,7 @@
 // Compared with one lane per block this turns 7 x 16-byte scattered loads per step per lane into 1 KB
 // contiguous wave loads and gives 64x more lanes of parallelism.
 #pragma once
+#include <type_traits>
 #include "chmc_core.h"
 
 namespace chmc {
@@ -360,13 +361,41 @@ __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int w
   // interval m of the block: only rows [m, nrows) are non-zero there (v_0 columns belong to interval 0)
   const int voff = bd.first ? sy.V0 : 0;
   const int per = sy.S * sy.V;
+  // 16-byte path: two columns per lane and iteration when every row and the vector are 16-byte aligned
+  const bool vec2 = ((sy.Q | sy.NV | sy.U | bd.col0 | voff | per) & 1) == 0;
+  auto interval = [&](auto m0c, int k0, int k1) {  // rows [M0, nrows) over columns [k0, k1)
+    constexpr int M0 = decltype(m0c)::value;
+    if (vec2) {
+      for (int k = k0 + 2 * lane; k < k1; k += 128) {
+        const double2_ x = *reinterpret_cast<const double2_*>(wv + k);
+#pragma unroll
+        for (int i = M0; i < RM; ++i)
+          if (i < bd.nrows) {
+            const double2_ j = *reinterpret_cast<const double2_*>(Jv + (size_t)i * sy.NV + k);
+            acc[i] += j.x * x.x + j.y * x.y;
+          }
+      }
+    } else {
+      for (int k = k0 + lane; k < k1; k += 64) {
+        const double x = wv[k];
+#pragma unroll
+        for (int i = M0; i < RM; ++i)
+          if (i < bd.nrows) acc[i] += Jv[(size_t)i * sy.NV + k] * x;
+      }
+    }
+  };
   for (int m = 0; m < bd.nobs; ++m) {
     const int k0 = m == 0 ? 0 : voff + m * per, k1 = voff + (m + 1) * per;
-    for (int k = k0 + lane; k < k1; k += 64) {
-      const double x = wv[k];
-#pragma unroll
-      for (int i = 0; i < RM; ++i)
-        if (i >= m && i < bd.nrows) acc[i] += Jv[(size_t)i * sy.NV + k] * x;
+    // the first active row is a compile-time constant inside an interval (no per-row branches in the column loop)
+    switch (m < RM ? m : RM - 1) {
+      case 0: interval(std::integral_constant<int, 0>{}, k0, k1); break;
+      case 1: interval(std::integral_constant<int, (1 < RM ? 1 : RM - 1)>{}, k0, k1); break;
+      case 2: interval(std::integral_constant<int, (2 < RM ? 2 : RM - 1)>{}, k0, k1); break;
+      case 3: interval(std::integral_constant<int, (3 < RM ? 3 : RM - 1)>{}, k0, k1); break;
+      case 4: interval(std::integral_constant<int, (4 < RM ? 4 : RM - 1)>{}, k0, k1); break;
+      case 5: interval(std::integral_constant<int, (5 < RM ? 5 : RM - 1)>{}, k0, k1); break;
+      case 6: interval(std::integral_constant<int, (6 < RM ? 6 : RM - 1)>{}, k0, k1); break;
+      default: interval(std::integral_constant<int, (7 < RM ? 7 : RM - 1)>{}, k0, k1); break;  // rows 7.. of a 16-row block
     }
   }
 #pragma unroll
