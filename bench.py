@@ -174,7 +174,16 @@ def main():
         per_chain = {"newton_blk": 8.0 * (3 * nnz + 2 * Q), "state_blk": 8.0 * (2 * nnz + 2 * Q),
                      "grad_log_det_blk": 8.0 * (4 * nnz + 2 * Q), "update": 8.0 * (nnz + 6 * Q),
                      "jacob_vec": 8.0 * (nnz + Q)}.get(name, 8.0 * 3 * Q)
-        achieved = per_chain * B / (avg_ms * 1e-3) / 1e9
+        # chains one launch processes: the Newton-loop kernels are masked per chain, so the later iterations of a solve
+        # (and the one speculatively enqueued iteration that finds every chain converged) touch only the chains still
+        # active.  For newton_blk the (chain, iteration) pairs of the timed region are known exactly from the
+        # per-chain iteration counters; the other classes run over every chain.
+        launches_all = nl[dom] * a.profile_stride
+        if name == "newton_blk" and nl[dom]:
+            chains_per_launch = float(itf.sum() + itb.sum()) / launches_all
+        else:
+            chains_per_launch = float(B)
+        achieved = per_chain * chains_per_launch / (avg_ms * 1e-3) / 1e9 if nl[dom] else float("nan")
         traffic = None
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
@@ -200,7 +209,9 @@ def main():
             },
             "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": per_chain * B, "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": per_chain * chains_per_launch,
+                         "algorithmic_bytes_per_chain": per_chain, "chains_per_launch": chains_per_launch,
+                         "avg_launch_ms": avg_ms,
                          "launches_timed": int(nl[dom]), "timed_every": a.profile_stride},
         }
         if world == 1 and not a.no_cpu_baseline:
