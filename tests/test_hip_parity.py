@@ -150,3 +150,69 @@ def test_switch_partition_matches_oracle():
         assert np.abs(xo[c] - xo_o).max() < 1e-12
         assert abs(ctx.log_det_sqrt_gram()[c] - ch.log_det()) < 1e-10
     ctx.close()
+
+
+# ---- the hand-scheduled forward scan (k_fwd_scan) runs when the steps per observation are a multiple of 8
+SCAN = [
+    # model, T, S, R, noisy, gaussian
+    ("fhn", 6, 8, 2, True, False),
+    ("fhn", 7, 16, 3, False, False),
+    ("fhn", 6, 8, 2, True, True),
+    ("sir", 14, 8, 14, True, False),
+    ("sir", 6, 16, 2, True, False),
+]
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy,gaussian", SCAN)
+def test_ops_forward_scan_kernel(model, T, S, R, noisy, gaussian):
+    """23 chains: B * K is neither a multiple of 64 nor below it for the partitioned cases, so full, partial and
+    (for K = 1) single workgroups of the scan are all exercised."""
+    case = make_case(model, T, S, R, noisy, B=23, seed=21, gaussian=gaussian)
+    ctx = make_ctx(case)
+    check_ops_against_oracle(ctx, case)
+    ctx.close()
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy,gaussian", SCAN)
+def test_steps_forward_scan_kernel(model, T, S, R, noisy, gaussian):
+    case = make_case(model, T, S, R, noisy, B=5, seed=22, gaussian=gaussian)
+    ctx = make_ctx(case)
+    dts = np.array([0.05, -0.05, 0.1, 0.02, -0.08])
+    check_steps_against_oracle(ctx, case, dts, newton=True, n_steps=3)
+    ctx.close()
+
+
+def test_forward_scan_kernel_matches_generic_functor(monkeypatch):
+    """Same inputs through both forward-scan implementations: constraint values, Jacobian (which is built from the
+    stored trajectory) and two leapfrog steps with a masked chain.  The arithmetic per step is the same generated
+    code, so only FMA contraction can differ: 1e-13 relative."""
+    case = make_case("fhn", 9, 16, 3, True, B=70, seed=23)
+    rng = np.random.default_rng(5)
+    p = rng.standard_normal(case["q"].shape)
+    qq = np.repeat(case["q"][:1], 70, 0)
+    xx = np.repeat(case["x_obs"][:1], 70, 0)
+    dts = 0.02 + 0.08 * rng.random(70)
+    act = np.ones(70, dtype=np.int32)
+    act[[3, 64, 69]] = 0
+    out = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("CHMC_NO_FWD_SCAN", "1")
+        else:
+            monkeypatch.delenv("CHMC_NO_FWD_SCAN", raising=False)
+        ctx = make_ctx(case)
+        ctx.set_state(case["q"], p, case["x_obs"], 1)
+        c = ctx.constr()
+        du, dv = ctx.jacob_constr_blocks()
+        ctx.set_state(qq, p, xx, 0)
+        ctx.project_onto_cotangent_space()
+        res = [ctx.leapfrog_step(dts, active=act) for _ in range(2)]
+        q1, p1, _, _ = ctx.get_state()
+        out.append((c, du, dv, q1, p1, res))
+        ctx.close()
+    a, b = out
+    for x, y in zip(a[:5], b[:5]):
+        assert np.abs(x - y).max() <= 1e-13 * max(1.0, np.abs(y).max())
+    for ra, rb in zip(a[5], b[5]):
+        assert np.array_equal(ra["status"], rb["status"]) and np.array_equal(ra["iters_fwd"], rb["iters_fwd"])
+        assert (ra["status"][[3, 64, 69]] == -1).all()
