@@ -17,7 +17,7 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 n_iter = int(sys.argv[3]) if len(sys.argv) > 3 else 150
 n_warm = int(sys.argv[4]) if len(sys.argv) > 4 else 50
 t0 = time.time()
-wl = FhnWorkload(B, num_steps_per_obs=S)
+wl = FhnWorkload(B, num_steps_per_obs=S, device_init=True)  # initial states solved on the device
 print(f"set-up {time.time() - t0:.1f} s: {B} chains, dim_q = {wl.ctx.Q}", flush=True)
 t0 = time.time()
 res = sample_static_chmc(wl.ctx, n_iter, 16, 0.1, seed=wl.seed, n_adapt=n_warm,

@@ -68,6 +68,13 @@ int chmc_get_blocks(const chmc_ctx* ctx, int partition, int* out);
  * :1151-1184). */
 int chmc_set_state(chmc_ctx* ctx, const double* q, const double* p, const double* x_obs_seq, int partition);
 int chmc_get_state(chmc_ctx* ctx, double* q, double* p, double* x_obs_seq, int* partition);
+/* find_initial_state_by_linear_interpolation (sde/mici_extensions.py:1479-1547) for all chains at once, on the
+ * device: given u [B][U], v_0 [B][V0] and full states at the observation times x_obs_seq_init [B][T][X]
+ * (generate_x_obs_seq_init of the scripts), solves per time step for the noise increments that make the discretised
+ * path interpolate linearly between them (solve_for_v_seq :1503-1526), sets pos = [u | v_0 | v_seq | n = 0],
+ * mom = 0, x_obs_seq = x_obs_seq_init and evaluates the state caches, like chmc_set_state. */
+int chmc_init_linear_interpolation(chmc_ctx* ctx, const double* u, const double* v_0, const double* x_obs_seq_init,
+                                   int partition);
 int chmc_set_momentum(chmc_ctx* ctx, const double* p);
 int chmc_get_state_device(chmc_ctx* ctx, void* q_dev, void* p_dev);  /* device-to-device copies */
 int chmc_set_momentum_device(chmc_ctx* ctx, const void* p_dev);

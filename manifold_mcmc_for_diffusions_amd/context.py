@@ -72,6 +72,17 @@ class ChmcContext:
         check(self.L.chmc_set_state(self.h, ptr(q), ptr(p), ptr(xo), int(partition)), "chmc_set_state")
         self.partition = int(partition)
 
+    def init_by_linear_interpolation(self, u, v_0, x_obs_seq_init, partition=0):
+        """find_initial_state_by_linear_interpolation (sde/mici_extensions.py:1479-1547) for every chain, on the
+        device: u [B, U], v_0 [B, V0], x_obs_seq_init [B, T, X]."""
+        u, v_0, xo = as_c(u), as_c(v_0), as_c(x_obs_seq_init)
+        if u.shape != (self.B, self.U) or v_0.shape != (self.B, self.V0) or xo.shape != (self.B, self.T, self.X):
+            raise ValueError(f"expected u ({self.B}, {self.U}), v_0 ({self.B}, {self.V0}), "
+                             f"x_obs_seq_init ({self.B}, {self.T}, {self.X})")
+        check(self.L.chmc_init_linear_interpolation(self.h, ptr(u), ptr(v_0), ptr(xo), int(partition)),
+              "chmc_init_linear_interpolation")
+        self.partition = int(partition)
+
     def get_state(self, want_p=True, want_x_obs=True):
         q = np.empty((self.B, self.Q))
         p = np.empty((self.B, self.Q)) if want_p else None

@@ -1361,6 +1361,57 @@ struct KUpdate {
 };
 
 // ------------------------------------------------------------------------------------------
+// find_initial_state_by_linear_interpolation (:1479-1547), batched: one work item per (chain, time step).  The path
+// interpolates linearly between x_0 = generate_x_0(z, v_0) and the given states at the observation times; the
+// one-step map is affine in v with a square, full-rank d forward_func / d v, so the noise increment of a step is
+//   v_s = B(x_s)^-1 [ (x_{s+1} - x_s) - (forward_func(z, x_s, 0, delta) - x_s) ]          (solve_for_v_seq :1503-1526)
+// Writes q = [u | v_0 | v_seq | n = 0] (:1533-1540) into state slot 0.
+template <class M>
+struct KInitInterp {
+  Sys sy;
+  double* q;           // [B][Q]
+  const double* u;     // [B][U]
+  const double* v0;    // [B][V0]
+  const double* xobs;  // [B][T][X]  full states at the observation times (generate_x_obs_seq_init)
+  CHMC_HD void operator()(int tid) const {
+    constexpr int X = M::X, V = M::V;
+    static_assert(X == V, "the interpolation solve needs a square noise matrix");
+    const int TS = sy.T * sy.S;
+    const int c = tid / TS, s = tid - c * TS;
+    const int t = s / sy.S, i = s - t * sy.S;
+    double* qc = q + (size_t)c * sy.Q;
+    const double* uc = u + (size_t)c * sy.U;
+    ChainConsts<M> cc;
+    cc.init(uc, sy.dl);
+    double xa[X], xs[X], dlt[X], f0[X], zero[V], A[X * X], Bm[X * V], rhs[X];
+    if (t == 0) {
+      M::gx0(cc.z, v0 + (size_t)c * sy.V0, xa);
+    } else {
+      for (int a = 0; a < X; ++a) xa[a] = xobs[((size_t)c * sy.T + t - 1) * X + a];
+    }
+    for (int a = 0; a < X; ++a) {
+      dlt[a] = (xobs[((size_t)c * sy.T + t) * X + a] - xa[a]) / sy.S;
+      xs[a] = xa[a] + i * dlt[a];
+    }
+    for (int a = 0; a < V; ++a) zero[a] = 0.0;
+    M::step(cc.k, xs, zero, f0);
+    M::jac_ab(cc.k, xs, zero, A, Bm);
+    for (int a = 0; a < X; ++a) rhs[a] = dlt[a] - (f0[a] - xs[a]);
+    int piv[X];
+    lu_factor<X>(Bm, piv);
+    lu_solve<X, 1>(Bm, piv, rhs);
+    double* vq = qc + sy.U + sy.V0 + (size_t)s * V;
+    for (int a = 0; a < V; ++a) vq[a] = rhs[a];
+    if (s == 0) {
+      for (int a = 0; a < sy.U; ++a) qc[a] = uc[a];
+      for (int a = 0; a < sy.V0; ++a) qc[sy.U + a] = v0[(size_t)c * sy.V0 + a];
+      if (sy.noisy)
+        for (int a = 0; a < sy.T; ++a) qc[sy.U + sy.NV + a] = 0.0;
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------
 // Counter-based normal generator for the momentum refresh (IndependentMomentumTransition -> sample_momentum,
 // :1256-1259): Philox4x32-10 (Salmon et al. 2011) keyed by the seed, counter = (component pair, draw index,
 // global chain id), two 53-bit uniforms -> Box-Muller.  Stateless, so any sharding of the chains over GPUs and

@@ -43,26 +43,38 @@ def find_initial_state_by_linear_interpolation(model, obs_interval, num_steps_pe
     return np.concatenate(parts), x_obs_seq
 
 
-def fhn_initial_states(model, obs_interval, num_steps_per_obs, y_seq, num_chains, noisy, seed=20200710,
-                       chain_offset=0, total_chains=None):
-    """Initial states for `num_chains` FitzHugh-Nagumo chains as in
-    scripts/fhn_model_noisy_obs_chmc_experiment.py:105-117, one independent generator per chain
-    (SeedSequence(seed).spawn(total)[chain]) so that any sharding of the chains over ranks gives the same states.
-    Returns q [B, Q], x_obs_seq [B, T, X], and the per-chain generators (next draw: the momentum)."""
+def fhn_initial_draws(model, y_seq, num_chains, seed=20200710, chain_offset=0, total_chains=None):
+    """The random inputs of the FitzHugh-Nagumo initial states (scripts/fhn_model_noisy_obs_chmc_experiment.py:105-117),
+    one independent generator per chain (SeedSequence(seed).spawn(total)[chain]) so that any sharding of the chains
+    over ranks gives the same draws: u [B, Z], v_0 [B, V0], x_obs_seq_init [B, T, X] = [y, 0.5 N(0, 1)], generators."""
     y_seq = np.asarray(y_seq, dtype=np.float64).reshape((-1, 1))
     total = num_chains + chain_offset if total_chains is None else total_chains
     seqs = np.random.SeedSequence(seed).spawn(total)[chain_offset:chain_offset + num_chains]
     rngs = [np.random.default_rng(s) for s in seqs]
-
-    def gen_init(rng):  # :105-106
-        return np.concatenate((y_seq, rng.standard_normal(y_seq.shape) * 0.5), -1)
-
-    qs, xos = [], []
+    us, v0s, xos = [], [], []
     for rng in rngs:
-        u = rng.standard_normal(model.dim_z)
-        v_0 = rng.standard_normal(model.dim_v)  # sic: the script draws dim_v, equal to dim_v_0 for this model (:112)
-        q, xo = find_initial_state_by_linear_interpolation(model, obs_interval, num_steps_per_obs, y_seq, rng,
-                                                           gen_init, noisy, u=u, v_0=v_0)
+        us.append(rng.standard_normal(model.dim_z))
+        v0s.append(rng.standard_normal(model.dim_v))  # sic: the script draws dim_v, equal to dim_v_0 for this model (:112)
+        xos.append(np.concatenate((y_seq, rng.standard_normal(y_seq.shape) * 0.5), -1))  # :105-106
+    return np.stack(us), np.stack(v0s), np.stack(xos), rngs
+
+
+def fhn_initial_states(model, obs_interval, num_steps_per_obs, y_seq, num_chains, noisy, seed=20200710,
+                       chain_offset=0, total_chains=None):
+    """Initial states for `num_chains` FitzHugh-Nagumo chains on the host (NumPy).
+    Returns q [B, Q], x_obs_seq [B, T, X], and the per-chain generators (next draw: the momentum)."""
+    us, v0s, xos, rngs = fhn_initial_draws(model, y_seq, num_chains, seed, chain_offset, total_chains)
+    qs = []
+    for u, v_0, xo in zip(us, v0s, xos):
+        q, _ = find_initial_state_by_linear_interpolation(model, obs_interval, num_steps_per_obs, y_seq, None,
+                                                          lambda rng, xo=xo: xo, noisy, u=u, v_0=v_0)
         qs.append(q)
-        xos.append(xo)
-    return np.stack(qs), np.stack(xos), rngs
+    return np.stack(qs), xos, rngs
+
+
+def fhn_initial_states_device(ctx, model, y_seq, seed=20200710, chain_offset=0, total_chains=None, partition=0):
+    """The same initial states solved on the device for all chains at once (`chmc_init_linear_interpolation`); the
+    state stays resident, nothing but the O(B T) draws crosses PCIe.  Returns the per-chain generators."""
+    us, v0s, xos, rngs = fhn_initial_draws(model, y_seq, ctx.B, seed, chain_offset, total_chains)
+    ctx.init_by_linear_interpolation(us, v0s, xos, partition)
+    return rngs

@@ -3,7 +3,7 @@ multi-GPU driver): data simulation, contexts, initial states, momentum refresh, 
 import numpy as np
 from . import example_models as em
 from .context import ChmcContext
-from .init import fhn_initial_states
+from .init import fhn_initial_states, fhn_initial_states_device
 
 SEED = 20200710  # scripts/utils.py:75-77
 
@@ -15,17 +15,21 @@ class FhnWorkload:
 
     def __init__(self, num_chains, num_steps_per_obs=400, num_obs=100, num_obs_per_subseq=5, sigma=0.1,
                  obs_interval=0.2, device=0, chain_offset=0, total_chains=None, use_gaussian_splitting=False,
-                 num_steps_per_obs_data=10000, seed=SEED):
+                 num_steps_per_obs_data=10000, seed=SEED, device_init=False):
         self.B, self.S, self.T, self.R = num_chains, num_steps_per_obs, num_obs, num_obs_per_subseq
         self.sigma, self.obs_interval = sigma, obs_interval
         self.seed, self.chain_offset = seed, chain_offset
         self.y = em.simulate_fhn_observations(num_obs, obs_interval, num_steps_per_obs_data, seed=seed, sigma=sigma)
         self.ctx = ChmcContext("fhn", obs_interval, num_steps_per_obs, num_obs_per_subseq, self.y[:, 0], sigma=sigma,
                                use_gaussian_splitting=use_gaussian_splitting, num_chains=num_chains, device=device)
-        q, xo, self.rngs = fhn_initial_states(em.fhn, obs_interval, num_steps_per_obs, self.y, num_chains,
-                                              sigma is not None, seed=seed, chain_offset=chain_offset,
-                                              total_chains=total_chains)
-        self.ctx.set_state(q, None, xo, 0)
+        if device_init:  # same states, solved on the device (no [B, Q] host array, no 8 B Q byte upload)
+            self.rngs = fhn_initial_states_device(self.ctx, em.fhn, self.y, seed=seed, chain_offset=chain_offset,
+                                                  total_chains=total_chains)
+        else:
+            q, xo, self.rngs = fhn_initial_states(em.fhn, obs_interval, num_steps_per_obs, self.y, num_chains,
+                                                  sigma is not None, seed=seed, chain_offset=chain_offset,
+                                                  total_chains=total_chains)
+            self.ctx.set_state(q, None, xo, 0)
         self.solver = dict(newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10, max_iters=50,
                            reverse_check_tol=2e-8)  # scripts/utils.py:131-166
         self._torch_gen = None

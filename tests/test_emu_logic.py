@@ -91,3 +91,27 @@ def test_api_misuse_is_reported(emu_lib):
         ctx.set_state(case["q"], None, case["x_obs"], 0)
         ctx.leapfrog_step(0.1, n_inner_step=2)
     ctx.close()
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy", [("fhn", 6, 8, 2, True), ("fhn", 5, 7, None, False), ("sir", 6, 5, 3, True)])
+def test_init_by_linear_interpolation_matches_host(emu_lib, model, T, S, R, noisy):
+    """chmc_init_linear_interpolation against the NumPy restatement of sde/mici_extensions.py:1479-1547 (init.py)."""
+    from manifold_mcmc_for_diffusions_amd import example_models as em, init
+    case = make_case(model, T, S, R, noisy, B=3, seed=31)
+    m = em.MODELS[model]
+    rng = np.random.default_rng(7)
+    u = case["q"][:, :4].copy()
+    v0 = case["q"][:, 4:4 + m.dim_v_0].copy()
+    xo = case["x_obs"] + 0.05 * rng.standard_normal(case["x_obs"].shape)
+    ctx = make_ctx(case)
+    ctx.init_by_linear_interpolation(u, v0, xo, partition=ctx.num_partition - 1)
+    q, p, xo_d, part = ctx.get_state()
+    assert part == ctx.num_partition - 1 and np.array_equal(xo_d, xo) and not p.any()
+    for c in range(3):
+        qh, _ = init.find_initial_state_by_linear_interpolation(m, case["obs_interval"], S, case["y"], None,
+                                                                lambda r, c=c: xo[c], noisy, u=u[c], v_0=v0[c])
+        assert np.abs(q[c] - qh).max() <= 1e-11 * max(1.0, np.abs(qh).max())
+    # the interpolated path hits the given states at the observation times
+    ctx.update_x_obs_seq()
+    assert np.abs(ctx.get_state()[2] - xo).max() <= 1e-9 * (1.0 + np.abs(xo).max())
+    ctx.close()

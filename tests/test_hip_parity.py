@@ -216,3 +216,40 @@ def test_forward_scan_kernel_matches_generic_functor(monkeypatch):
     for ra, rb in zip(a[5], b[5]):
         assert np.array_equal(ra["status"], rb["status"]) and np.array_equal(ra["iters_fwd"], rb["iters_fwd"])
         assert (ra["status"][[3, 64, 69]] == -1).all()
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy", [("fhn", 6, 8, 2, True), ("fhn", 5, 7, None, False), ("sir", 6, 5, 3, True)])
+def test_device_initial_states_match_host(model, T, S, R, noisy):
+    """chmc_init_linear_interpolation (sde/mici_extensions.py:1479-1547, batched) against init.py's NumPy version,
+    and the manifold property of the result: the path interpolates the given states."""
+    from manifold_mcmc_for_diffusions_amd import example_models as em, init
+    case = make_case(model, T, S, R, noisy, B=5, seed=31)
+    m = em.MODELS[model]
+    rng = np.random.default_rng(7)
+    u = case["q"][:, :4].copy()
+    v0 = case["q"][:, 4:4 + m.dim_v_0].copy()
+    xo = case["x_obs"] + 0.05 * rng.standard_normal(case["x_obs"].shape)
+    ctx = make_ctx(case)
+    ctx.init_by_linear_interpolation(u, v0, xo, partition=0)
+    q, p, xo_d, part = ctx.get_state()
+    assert part == 0 and np.array_equal(xo_d, xo) and not p.any()
+    for c in range(5):
+        qh, _ = init.find_initial_state_by_linear_interpolation(m, case["obs_interval"], S, case["y"], None,
+                                                                lambda r, c=c: xo[c], noisy, u=u[c], v_0=v0[c])
+        assert np.abs(q[c] - qh).max() <= 1e-11 * max(1.0, np.abs(qh).max())
+    # state rows of the constraint (x at the sub-sequence ends minus x_obs_seq) vanish on the interpolated path
+    ctx.update_x_obs_seq()
+    _, _, xo_full, _ = ctx.get_state()
+    assert np.abs(xo_full - xo).max() <= 1e-9 * (1.0 + np.abs(xo).max())
+    ctx.close()
+
+
+def test_workload_device_init_equals_host_init():
+    from manifold_mcmc_for_diffusions_amd.workload import FhnWorkload
+    a = FhnWorkload(num_chains=3, num_steps_per_obs=16, num_obs=10, num_steps_per_obs_data=200)
+    b = FhnWorkload(num_chains=3, num_steps_per_obs=16, num_obs=10, num_steps_per_obs_data=200, device_init=True)
+    qa, _, xa, _ = a.ctx.get_state()
+    qb, _, xb, _ = b.ctx.get_state()
+    assert np.array_equal(xa, xb) and np.abs(qa - qb).max() <= 1e-11 * max(1.0, np.abs(qa).max())
+    assert np.abs(a.ctx.hamiltonian() - b.ctx.hamiltonian()).max() <= 1e-7 * np.abs(a.ctx.hamiltonian()).max()
+    a.ctx.close(), b.ctx.close()
