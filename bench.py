@@ -142,7 +142,7 @@ def main():
         # the single gather of samples of a sampling segment: traced variables per chain (u, v_0, hamiltonian)
         ctx.get_state_device(qd.data_ptr(), None)
         ham = torch.from_numpy(ctx.hamiltonian()[:, :1]).to(dev)
-        return D.gather_samples(torch.cat([qd[:, :6], ham], 1).contiguous())
+        return D.gather_samples(torch.cat([qd[:, :6], ham], 1).contiguous(), equal_shards=True)
 
     gather_segment()  # untimed: first use loads torch's copy / cat kernels and sets up the communicator's buffers
     D.barrier()

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """End-to-end example on an MI355X: posterior sampling for the FitzHugh-Nagumo model with noisy observations
 (the configuration of scripts/fhn_model_noisy_obs_chmc_experiment.py in the reference: T = 100 observations,
-R = 5, sigma_y = 0.1) with batched constrained HMC.   usage: fhn_noisy_chmc.py [chains] [S] [iters] [warm-up]"""
+R = 5, sigma_y = 0.1) with batched constrained HMC.   usage: fhn_noisy_chmc.py [chains] [S] [iters] [warm-up] [output dir]
+With an output directory the traced variables of the reference's trace function (sigma, epsilon, gamma, beta, x_0,
+hamiltonian) are written as memory-mapped `.npy` files together with `summary.json`."""
 import os
 import sys
 import time
@@ -16,11 +18,20 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 n_iter = int(sys.argv[3]) if len(sys.argv) > 3 else 150
 n_warm = int(sys.argv[4]) if len(sys.argv) > 4 else 50
+out_dir = sys.argv[5] if len(sys.argv) > 5 else None
+
+
+def trace_func(head, ham):  # scripts/fhn_model_noisy_obs_chmc_experiment.py:82-99
+    z = em.fhn.generate_z(head[:, :4])
+    return {"σ": z[:, 0], "ϵ": z[:, 1], "γ": z[:, 2], "β": z[:, 3], "x_0": em.fhn.generate_x_0(z, head[:, 4:6]),
+            "hamiltonian": ham}
+
+
 t0 = time.time()
 wl = FhnWorkload(B, num_steps_per_obs=S, device_init=True)  # initial states solved on the device
 print(f"set-up {time.time() - t0:.1f} s: {B} chains, dim_q = {wl.ctx.Q}", flush=True)
 t0 = time.time()
-res = sample_static_chmc(wl.ctx, n_iter, 16, 0.1, seed=wl.seed, n_adapt=n_warm,
+res = sample_static_chmc(wl.ctx, n_iter, 16, 0.1, seed=wl.seed, n_adapt=n_warm, trace_dir=out_dir, trace_func=trace_func,
                          callback=lambda it, h, a, e: (it % 10 == 0) and print(
                              f"  iter {it:4d} accept {a:.2f} step {e:.3f} z-median {np.median(em.fhn.generate_z(h[:, :4]), 0).round(3)}",
                              flush=True))
@@ -43,3 +54,7 @@ for k in range(4):
     print(f"  {names[k]:8s} true {truth[k]:.2f}  posterior mean {allv.mean():.3f} sd {allv.std():.3f}  "
           f"5%-95% [{np.quantile(allv, 0.05):.3f}, {np.quantile(allv, 0.95):.3f}]  split-free R-hat {rhat:.3f}")
 print(f"  x_0      true [-0.5, 0.2]  posterior mean {x0.reshape(-1, 2).mean(0).round(3)}")
+if out_dir:
+    sm = res["summary"]
+    print(f"traces and summary.json in {out_dir}: " + ", ".join(
+        f"{k} {sm['mean'][k]:.3f} (r_hat {sm['r_hat'][k]:.3f}, ess {sm['ess_bulk'][k]:.0f})" for k in ("σ", "ϵ", "γ", "β")))

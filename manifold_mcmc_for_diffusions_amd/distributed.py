@@ -44,9 +44,11 @@ def barrier():
         dist.barrier()
 
 
-def gather_samples(local, dst=0):
+def gather_samples(local, dst=0, equal_shards=False):
     """The single gather of a sampling segment: `local` is this rank's [B_local, n] sample block (numpy array or
-    torch tensor on the rank's device).  Returns the [B_total, n] array on rank `dst`, None elsewhere."""
+    torch tensor on the rank's device).  Returns the [B_total, n] array on rank `dst`, None elsewhere.
+    equal_shards=True (every rank holds the same number of chains, as in bench.py) skips the exchange of the shard
+    sizes: the segment then costs exactly one collective."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
@@ -58,9 +60,12 @@ def gather_samples(local, dst=0):
     if backend == "gloo" and t.is_cuda:
         t = t.cpu()
     world, rank = dist.get_world_size(), dist.get_rank()
-    counts = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device))
-    counts = [int(c.item()) for c in counts]
+    if equal_shards:
+        counts = [t.shape[0]] * world
+    else:
+        counts = [torch.zeros(1, dtype=torch.int64, device=t.device) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device))
+        counts = [int(c.item()) for c in counts]
     if len(set(counts)) == 1:  # equal shards: one gather collective
         out = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
         dist.gather(t, out, dst=dst)

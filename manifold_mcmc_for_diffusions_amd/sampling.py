@@ -5,6 +5,7 @@ The reference drives the same integrator with Mici's dynamic multinomial (NUTS-s
 (scripts/utils.py:292-306); that transition is a caller of the hot path and out of this round's scope (SURVEY.md
 8f #2).  This static variant targets the same posterior (it is a valid Markov kernel for it) and exists to exercise
 the path end to end: momentum -> L constrained leapfrog steps -> accept / reject -> SwitchPartitionTransition."""
+import os
 import numpy as np
 
 
@@ -32,23 +33,58 @@ class DualAveragingStepSize:
         return float(np.exp(self.log_bar))
 
 
+def _mean_over_all_chains(local_sum, local_count):
+    """Mean of a per-chain statistic over the chains of every rank (one tiny all-reduce; SURVEY.md 8f #3: warm-up
+    adaptation combines the chains of all GPUs so that every rank integrates with the same step size)."""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from . import distributed as D
+            tot = D.sum_over_ranks([float(local_sum), float(local_count)])
+            return float(tot[0]) / float(tot[1])
+    except ImportError:
+        pass
+    return float(local_sum) / float(local_count)
+
+
 def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_adapt=0, solver=None, rng=None,
-                       n_head=6, callback=None):
+                       n_head=6, callback=None, trace_dir=None, trace_func=None, total_chains=None):
     """Runs n_iter transitions on all chains of `ctx`; returns traces of the first `n_head` position components
     ([n_iter, B, n_head]), accept statistics and the step size used.  Directions are sampled per chain and
-    transition (forward / backward in time), failed trajectories are rejected."""
+    transition (forward / backward in time), failed trajectories are rejected.
+
+    trace_dir: write memory-mapped traces (`trace_<var>.npy`, [chain, draw, ...]) and `summary.json` there;
+    trace_func(head [B, n_head], hamiltonian [B]) -> {name: [B, ...]} chooses the traced variables (default: the
+    head components as `pos_head` and `hamiltonian`).  Under torch.distributed the accept statistic that drives the
+    step-size adaptation is averaged over the chains of all ranks; with `total_chains` (the number of chains of the
+    whole job) the per-chain directions and accept draws are taken from one stream indexed by the global chain
+    number, so that any sharding of the chains reproduces the single-process run."""
     solver = dict(newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10, max_iters=50,
                   reverse_check_tol=2e-8) if solver is None else solver
     rng = np.random.default_rng(seed) if rng is None else rng
     adapter = DualAveragingStepSize(step_size) if n_adapt > 0 else None
     B = ctx.B
+
+    def draw():  # uniforms of this rank's chains
+        if total_chains is None:
+            return rng.random(B)
+        return rng.random(total_chains)[chain_offset:chain_offset + B]
+
     heads = np.empty((n_iter, B, n_head))
     acc_hist, eps_hist, fail_hist = np.empty(n_iter), np.empty(n_iter), np.empty(n_iter)
+    if trace_func is None:
+        def trace_func(head, ham):
+            return {"pos_head": head, "hamiltonian": ham}
+    writer, t_start, c_start = None, None, None
+    if trace_dir is not None:
+        import time
+        from .traces import TraceWriter
+        t_start, c_start = time.perf_counter(), ctx.counters()
     for it in range(n_iter):
         ctx.sample_momentum(seed, it + 1, chain_offset)
         h0 = ctx.hamiltonian()[:, 0]
         ctx.snapshot()
-        dt = np.where(rng.random(B) < 0.5, step_size, -step_size)
+        dt = np.where(draw() < 0.5, step_size, -step_size)
         act = np.ones(B, dtype=np.int32)
         for _ in range(n_step):
             r = ctx.leapfrog_step(dt, active=act, **solver)
@@ -56,15 +92,31 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
         h1 = ctx.hamiltonian()[:, 0]
         dh = h1 - h0
         prob = np.where((act == 1) & np.isfinite(dh), np.exp(np.minimum(0.0, -np.where(np.isfinite(dh), dh, np.inf))), 0.0)
-        accept = rng.random(B) < prob
+        accept = draw() < prob
         ctx.restore((~accept).astype(np.int32))
         ctx.switch_partition()
         heads[it] = ctx.get_head(n_head)
-        acc_hist[it], eps_hist[it], fail_hist[it] = prob.mean(), step_size, 1.0 - act.mean()
+        if trace_dir is not None:
+            vals = {k: np.asarray(v) for k, v in trace_func(heads[it], ctx.hamiltonian()[:, 0]).items()}
+            if writer is None:
+                writer = TraceWriter(trace_dir, B, n_iter, {k: v.shape[1:] for k, v in vals.items()})
+            writer.write(it, vals)
+        acc_all = _mean_over_all_chains(prob.sum(), B)
+        acc_hist[it], eps_hist[it], fail_hist[it] = acc_all, step_size, 1.0 - act.mean()
         if adapter is not None and it < n_adapt:
-            step_size = adapter.update(prob.mean())
+            step_size = adapter.update(acc_all)
             if it == n_adapt - 1:
                 step_size = adapter.final()
         if callback is not None:
             callback(it, heads[it], prob.mean(), step_size)
-    return dict(heads=heads, accept_stat=acc_hist, step_size=eps_hist, fail_rate=fail_hist, final_step_size=step_size)
+    out = dict(heads=heads, accept_stat=acc_hist, step_size=eps_hist, fail_rate=fail_hist, final_step_size=step_size)
+    if writer is not None:
+        import time
+        from .traces import save_summary
+        writer.flush()
+        c_end = ctx.counters()
+        main = {k: np.asarray(v)[:, n_adapt:] for k, v in writer.arrays().items()}  # summary over the post-warm-up draws
+        out["summary"] = save_summary(trace_dir, main, None, time.perf_counter() - t_start, step_size,
+                                      {k: c_end[k] - c_start[k] for k in c_end if k != "_"})
+        out["trace_files"] = {k: os.path.join(trace_dir, f"trace_{k}.npy") for k in writer.arrays()}
+    return out

@@ -44,6 +44,36 @@ def test_two_ranks_equal_one_rank(emu_lib, tmp_path, total):  # noqa: F811
     np.testing.assert_array_equal(gathered, single)
 
 
+def test_two_ranks_adapt_one_step_size(emu_lib, tmp_path):  # noqa: F811
+    """Sampler with dual-averaging warm-up on two ranks: the accept statistic is combined over the chains of both
+    ranks (one all-reduce per transition), so both ranks use the same step sizes, and with the chain-indexed random
+    streams the sharded run reproduces the single-process run."""
+    import dist_worker
+    total, n_iter = 4, 6
+    single = dist_worker.run_sampler(total, n_iter, 0, 1)
+    out = str(tmp_path / "gathered.npy")
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), out, str(total),
+                                       str(n_iter), "sampler"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise
+        assert p.returncode == 0, o.decode()[-2000:]
+    gathered = np.load(out)
+    hist = gathered[:, 6:]
+    assert (hist == hist[0]).all()                       # every chain / rank saw the same step-size history
+    assert len(set(hist[0, :n_iter - 2])) > 2            # ... which did adapt
+    np.testing.assert_allclose(gathered, single, rtol=1e-12, atol=1e-12)
+
+
 def test_shard_chains():
     from manifold_mcmc_for_diffusions_amd.distributed import shard_chains
     for total in (1, 7, 256, 1024, 4096):

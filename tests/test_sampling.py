@@ -1,5 +1,6 @@
 """The minimal caller (sampling.py): snapshot / restore semantics and detailed-balance sanity on a tiny problem,
 through the TEST-ONLY emulation build (CPU)."""
+import os
 import numpy as np
 from test_emu_logic import emu_lib  # noqa: F401
 from helpers import make_case, make_ctx
@@ -47,3 +48,53 @@ def test_static_sampler_runs_and_adapts(emu_lib):  # noqa: F811
     assert np.abs(ctx.constr()).max() < 1e-8  # every retained state lies on the manifold
     assert res["final_step_size"] > 0
     ctx.close()
+
+
+def test_trace_files_and_summary(emu_lib, tmp_path):  # noqa: F811
+    """trace_dir output: memory-mapped [chain, draw, ...] arrays per traced variable and a summary.json with the
+    reference's run totals (scripts/utils.py:368-381)."""
+    import json
+    from manifold_mcmc_for_diffusions_amd.sampling import sample_static_chmc
+    from manifold_mcmc_for_diffusions_amd import example_models as em
+    from manifold_mcmc_for_diffusions_amd.init import fhn_initial_states
+    from manifold_mcmc_for_diffusions_amd.context import ChmcContext
+    y = em.simulate_fhn_observations(6, 0.2, 50, seed=5, sigma=0.1)
+    ctx = ChmcContext("fhn", 0.2, 4, 2, y[:, 0], sigma=0.1, num_chains=3)
+    q, xo, _ = fhn_initial_states(em.fhn, 0.2, 4, y, 3, True, seed=7)
+    ctx.set_state(q, None, xo, 0)
+
+    def trace_func(head, ham):  # scripts/fhn_model_noisy_obs_chmc_experiment.py:82-99
+        z = np.stack([em.fhn.generate_z(u) for u in head[:, :4]])
+        return {"σ": z[:, 0], "ϵ": z[:, 1], "γ": z[:, 2], "β": z[:, 3], "hamiltonian": ham,
+                "x_0": np.stack([em.fhn.generate_x_0(zz, v) for zz, v in zip(z, head[:, 4:6])])}
+
+    d = str(tmp_path / "out")
+    res = sample_static_chmc(ctx, 10, 2, 0.05, seed=3, n_adapt=4, trace_dir=d, trace_func=trace_func)
+    x0 = np.load(os.path.join(d, "trace_x_0.npy"), mmap_mode="r")
+    sig = np.load(os.path.join(d, "trace_σ.npy"))
+    assert x0.shape == (3, 10, 2) and sig.shape == (3, 10)
+    np.testing.assert_array_equal(x0[:, -1], trace_func(res["heads"][-1], np.zeros(3))["x_0"])
+    s = json.load(open(os.path.join(d, "summary.json")))
+    assert {"mean", "sd", "r_hat", "ess_bulk", "total_sampling_time", "final_integrator_step_size",
+            "total_leapfrog_step_calls", "total_constr_calls"} <= set(s)
+    assert s["total_leapfrog_step_calls"] == 10 * 2 and "x_0[1]" in s["mean"] and "σ" in s["sd"]
+    assert s["final_integrator_step_size"] == res["final_step_size"]
+    ctx.close()
+
+
+def test_rhat_and_ess_on_known_processes():
+    from manifold_mcmc_for_diffusions_amd.traces import split_rhat_and_ess, summarize
+    rng = np.random.default_rng(0)
+    iid = rng.standard_normal((8, 2000))
+    r, e = split_rhat_and_ess(iid)
+    assert abs(r - 1.0) < 0.01 and 0.8 * 16000 < e < 1.25 * 16000
+    ar = np.zeros((8, 4000))  # AR(1), rho = 0.9: ESS = N (1 - rho) / (1 + rho)
+    eps = rng.standard_normal(ar.shape)
+    for t in range(1, ar.shape[1]):
+        ar[:, t] = 0.9 * ar[:, t - 1] + eps[:, t]
+    r, e = split_rhat_and_ess(ar)
+    assert abs(r - 1.0) < 0.05 and 0.6 < e / (32000 * 0.1 / 1.9) < 1.6
+    shifted = iid + np.arange(8)[:, None]  # chains that disagree
+    assert split_rhat_and_ess(shifted)[0] > 1.5
+    s = summarize({"a": iid, "b": np.stack([iid, ar[:, :2000]], -1)})
+    assert set(s["mean"]) == {"a", "b[0]", "b[1]"}
