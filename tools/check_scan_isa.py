@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Guard for the hand-issued loads of k_fwd_scan (csrc/chmc_wave.h).
+
+The forward scan issues its `global_load_dwordx4` through inline asm and waits with counted `s_waitcnt vmcnt(N)`
+statements that the compiler knows nothing about, so nothing but register allocation keeps the compiler from
+touching a destination register while its load is still in flight (a spill, a copy to an AGPR or a re-materialised
+move would read stale data without any diagnostic).  This script compiles the device code to assembly and replays
+every k_fwd_scan kernel's instruction stream:
+
+  * asm loads enter a FIFO (loads retire in issue order), a counted wait pops it down to N entries, vmcnt(0) empties it;
+  * any other instruction that reads or writes a register of a load still in the FIFO is a violation;
+  * the kernels must not use scratch memory.
+
+Loop bodies are replayed twice so that registers carried around the back edge are covered.
+usage: check_scan_isa.py [chmc.hip]      exit status 0 = clean"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1):
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+        else:
+            out.add(int(m.group(3)))
+    return out
+
+
+def check_kernel(name, body):
+    problems = []
+    if any("scratch_" in l for l in body):
+        problems.append("uses scratch memory")
+    # instruction stream with asm markers resolved
+    stream, in_asm = [], False
+    for l in body:
+        t = l.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if t.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not t or t.startswith((";", ".")) or t.endswith(":"):
+            if t.endswith(":"):
+                stream.append(("label", t[:-1], False))
+            continue
+        stream.append(("ins", t, in_asm))
+    # replay; loops: a backward branch target seen earlier -> replay that span once more
+    labels = {t: i for i, (k, t, _) in enumerate(stream) if k == "label"}
+    order = list(range(len(stream)))
+    for i, (k, t, _) in enumerate(stream):
+        if k == "ins" and t.startswith("s_cbranch"):
+            tgt = t.split()[-1]
+            if tgt in labels and labels[tgt] < i:
+                order += list(range(labels[tgt], i + 1))
+    fifo = []  # list of register sets of in-flight asm loads
+    n_loads = 0
+    for idx in order:
+        k, t, in_asm = stream[idx]
+        if k != "ins":
+            continue
+        if in_asm and t.startswith("global_load_dwordx4"):
+            dst = regs_of(t.split(",")[0])
+            fifo.append(dst)
+            n_loads += 1
+            continue
+        m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
+        if m:
+            n = int(m.group(1))
+            if in_asm:
+                del fifo[: max(0, len(fifo) - n)]
+            elif n == 0:
+                fifo.clear()
+            continue
+        if t.startswith(("s_", "ds_")) and "v" not in t.split(None, 1)[-1]:
+            continue
+        if fifo:
+            used = regs_of(t.split(None, 1)[1] if " " in t else "")
+            for dst in fifo:
+                if used & dst:
+                    problems.append(f"touches in-flight load registers {sorted(used & dst)[:4]}: {t}")
+                    break
+    if n_loads == 0:
+        problems.append("no hand-issued loads found (kernel changed?)")
+    return problems
+
+
+def main():
+    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "manifold_mcmc_for_diffusions_amd", "csrc", "chmc.hip")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "chmc.s")
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-S", "--cuda-device-only",
+                               "-o", out, src])
+        lines = open(out).read().split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN4chmc10k_fwd_scan\w*:", l)]
+    bad = 0
+    for s in starts:
+        e = next(i for i in range(s, len(lines)) if lines[i].strip().startswith(".amdhsa_kernel"))
+        name = lines[s].split(":")[0]
+        probs = check_kernel(name, lines[s:e])
+        print(("FAIL " if probs else "ok   ") + name)
+        for p in probs[:10]:
+            print("     " + p)
+        bad += bool(probs)
+    if not starts:
+        print("no k_fwd_scan kernels found")
+        return 2
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
