@@ -25,6 +25,20 @@ namespace chmc {
 // the non-temporal hint as well.
 __device__ inline double ld_stream(const double* p) { return __builtin_nontemporal_load(p); }
 
+// Stores the compiler does not see.  With one of its own stores pending, hipcc (ROCm 7.2) waits for vmcnt(0) at the
+// next use of a prefetched value, i.e. for the store acknowledgement, every tile.  A store issued through inline asm
+// is not tracked, so the waits for the prefetched loads keep their counts (which stay valid: an untracked younger
+// store only makes a counted wait retire more).  The trailing s_nop covers the wait states the hazard recogniser would
+// insert between a wide store and a VALU write of its data registers.
+__device__ __forceinline__ void st_async(double* p, double v) {
+  asm volatile("global_store_dwordx2 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void st_async2(double* p, double v0, double v1) {
+  typedef double d2v __attribute__((ext_vector_type(2)));
+  const d2v v = {v0, v1};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+
 __device__ inline double bcast0(double x) {  // value of lane 0, as a wave-uniform value
   union { double d; int i[2]; } u;
   u.d = x;
@@ -189,9 +203,14 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
     if (MODE == 0) {
       if (r.valid) {
 #pragma unroll URM
-        for (int i = 0; i < RM; ++i)
+        for (int i = 0; i < RM; ++i) {
+          if (V == 2) {
+            st_async2(Jo + (size_t)i * NV + col, jr[i * V], jr[i * V + 1]);
+          } else {
 #pragma unroll
-          for (int d = 0; d < V; ++d) Jo[(size_t)i * NV + col + d] = jr[i * V + d];
+            for (int d = 0; d < V; ++d) st_async(Jo + (size_t)i * NV + col + d, jr[i * V + d]);
+          }
+        }
       }
 #pragma unroll URM
       for (int i = 0; i < RM; ++i)
@@ -588,7 +607,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
           for (int i = 0; i < RM; ++i)
             if (i >= j && i < bd.nrows) {
 #pragma unroll
-              for (int a = 0; a < X; ++a) Xd[(size_t)(i * X + a) * TS + s] = xs[i * X + a];
+              for (int a = 0; a < X; ++a) st_async(Xd + (size_t)(i * X + a) * TS + s, xs[i * X + a]);
             }
         }
       }
