@@ -53,6 +53,7 @@ struct Sys {
   const double* xobs;  // [B][T][X]
   const BlockDesc* blk;
   const int* obs2blk;
+  const int* order;  // [B * K] work item -> chain * K + block of the wave-per-block kernels (longest blocks first)
 };
 
 struct Slots {

@@ -71,7 +71,8 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= sy.B * sy.K) return;
-  const int c = wid / sy.K, b = wid - c * sy.K;
+  const int cbi = sy.order[wid];  // work order: longest blocks first
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
   if (MODE == 1 ? !w.nw[c] : !w.ok[c]) return;
   const BlockDesc bd = sy.blk[b];
   const int sl_ = sl.cur[c] ^ which;
@@ -366,7 +367,8 @@ __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int w
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= sy.B * sy.K) return;
-  const int c = wid / sy.K, b = wid - c * sy.K;
+  const int cbi = sy.order[wid];  // work order: longest blocks first
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
   if (!w.ok[c]) return;
   const BlockDesc bd = sy.blk[b];
   const int s = sl.cur[c] ^ which;
@@ -457,7 +459,8 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
   const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wid = blockIdx.x * 4 + wv_;
   if (wid >= sy.B * sy.K) return;
-  const int c = wid / sy.K, b = wid - c * sy.K;
+  const int cbi = sy.order[wid];  // work order: longest blocks first
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
   if (!w.ok[c]) return;
   const BlockDesc bd = sy.blk[b];
   const int s_ = sl.cur[c] ^ which;
@@ -649,7 +652,8 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
   const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wid = blockIdx.x * 4 + wv_;
   if (wid >= sy.B * sy.K) return;
-  const int c = wid / sy.K, b = wid - c * sy.K;
+  const int cbi = sy.order[wid];  // work order: longest blocks first
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
   if (!w.ok[c]) return;
   const BlockDesc bd = sy.blk[b];
   const int s_ = sl.cur[c] ^ which;
