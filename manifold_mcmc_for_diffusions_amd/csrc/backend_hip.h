@@ -195,7 +195,7 @@ static void launch_colmax(F f, int ncol, int B, int cls = 0) {
     if (g_prof_pending.size() > 4096) prof_drain();
   }
 }
-// wave kernels (chmc_wave.h): 4 wavefronts per 256-thread workgroup, one (chain, block) per wavefront
+// wave kernels (chmc_wave.h): one (chain, block) per wavefront
 template <class K, class... Args>
 static void launch_wave(K kern, long nwaves, int cls, Args... args) {
   if (nwaves <= 0) return;
@@ -205,7 +205,11 @@ static void launch_wave(K kern, long nwaves, int cls, Args... args) {
     r.a = prof_event(), r.b = prof_event(), r.cls = cls;
     note(hipEventRecord(r.a, g_stream));
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)((nwaves + 3) / 4)), dim3(256), 0, g_stream, args...);
+  // one wavefront per workgroup: a SIMD takes the next (chain, block) as soon as its wavefront retires instead of
+  // waiting for the other three of a 256-thread workgroup (reverse sweep -3 %); CHMC_WAVES_PER_BLOCK overrides
+  static const int wpb_env = getenv("CHMC_WAVES_PER_BLOCK") ? atoi(getenv("CHMC_WAVES_PER_BLOCK")) : 1;
+  static const int wpb = wpb_env >= 1 && wpb_env <= 4 ? wpb_env : 1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((nwaves + wpb - 1) / wpb)), dim3(64 * wpb), 0, g_stream, args...);
   note(hipGetLastError());
   if (prof) {
     note(hipEventRecord(r.b, g_stream));

@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   // it keeps its row loops rolled, the <= 8-row instantiations are fully unrolled
   constexpr int URM = RM <= 8 ? 64 : 1;
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wid = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];  // work order: longest blocks first
   const int c = cbi / sy.K, b = cbi - c * sy.K;
@@ -365,7 +365,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
 template <int RM>
 __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int which, int vsel) {
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wid = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];  // work order: longest blocks first
   const int c = cbi / sy.K, b = cbi - c * sy.K;
@@ -457,7 +457,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
   __shared__ double sm[4][RM * RM + RM * Z];
   const int lane = threadIdx.x & 63;
   const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wid = blockIdx.x * 4 + wv_;
+  const int wid = blockIdx.x * (blockDim.x >> 6) + wv_;
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];  // work order: longest blocks first
   const int c = cbi / sy.K, b = cbi - c * sy.K;
@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
   __shared__ double sm[4][RM * RM + RM * Z];
   const int lane = threadIdx.x & 63;
   const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wid = blockIdx.x * 4 + wv_;
+  const int wid = blockIdx.x * (blockDim.x >> 6) + wv_;
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];  // work order: longest blocks first
   const int c = cbi / sy.K, b = cbi - c * sy.K;
@@ -926,7 +926,7 @@ template <class M, int RM, int SYM, int TGT>
 __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work w, int which, int qsel, int psel) {
   constexpr int U = M::Z;
   const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int c = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (c >= sy.B) return;
   if (TGT == 0 ? !w.nw[c] : !w.ok[c]) return;
   const int s = sl.cur[c] ^ which;
