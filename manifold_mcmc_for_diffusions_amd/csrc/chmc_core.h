@@ -69,12 +69,15 @@ struct Slots {
   double* ldb[2];
   double* logdet[2];
   double* grad[2];
+  double* pg[2];  // [B][Q] P(q) dh1_dpos(q): the projected gradient of the slot's state (see chmc_leapfrog_step)
   int* cur;
 };
 
 struct Work {
   double* trajw;    // [B][TRJ]      trajectory of the Newton iterate
   double* cpad;     // [B][Kmax][RM] constraint values, block-padded
+  double* cpad2;    // [B][Kmax][RM] second right-hand side of a two-vector projection
+  double* lampad2;  // [B][Kmax][RM] multipliers of the first vector of a two-vector projection
   double* tpad;     // [B][Kmax][RM] D_b^-1 (rhs)_b
   double* lampad;   // [B][Kmax][RM] multipliers
   double* Ew;       // [B][Kmax][RM][U] D_b^-1 dc/du (current iterate)
@@ -1259,7 +1262,7 @@ struct KSolveChain {
       w.err[c] = bitsd(eb);
       w.ndq[c] = nb;
     } else if (TGT == 1) {
-      double* p = (psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
+      double* p = (psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : psel == 3 ? pick(sl.pg, s) : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
       for (int a = 0; a < U; ++a) p[a] -= du[a];
     }
   }
@@ -1291,6 +1294,12 @@ struct KUpdate {
   Work w;
   int which, qsel, psel;
   CHMC_HD bool active(int c) const { return TGT == 0 ? w.nw[c] != 0 : w.ok[c] != 0; }
+  CHMC_HD double ncol_part2(int c, int col) const {  // same with the first vector's multipliers (TGT 3)
+    const int t = col - sy.NV;
+    const int b = sy.obs2blk[t];
+    const int j = t - sy.blk[b].obs0;
+    return j < sy.blk[b].ny ? sy.sigma * w.lampad2[((size_t)c * sy.Kmax + b) * RM + j] : 0.0;
+  }
   CHMC_HD unsigned long long* red(int c) const { return TGT == 0 ? &w.ndq[c] : nullptr; }
   CHMC_HD double ncol_part(int c, int col) const {  // observation-noise columns: dc/dn = sigma on y rows (:601-608)
     const int t = col - sy.NV;
@@ -1303,8 +1312,11 @@ struct KUpdate {
     const int col = idx * VEC;
     const size_t qi = (size_t)c * sy.Q + sy.U + col;
     double* tgt = TGT == 0 ? (qsel ? w.qb : pick(sl.q, s ^ 1))
-                           : TGT == 1 ? (psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : pick(sl.p, s ^ 1)) : w.pb;
-    double d[VEC], old[VEC];
+                           : TGT == 1 ? (psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : psel == 3 ? pick(sl.pg, s) : pick(sl.p, s ^ 1))
+                           : TGT == 3 ? pick(sl.p, s) : w.pb;
+    double d[VEC], old[VEC], d2[VEC], old2[VEC];  // (d2, old2: first vector of TGT 3)
+    double* tgt2 = TGT == 3 ? pick(sl.p, s) : nullptr;
+    if (TGT == 3) tgt = pick(sl.pg, s);  // TGT 3: p (multipliers lampad2) and pg (multipliers lampad) in one pass
     // issue the read-modify-write operands together with the Jacobian rows
     if (TGT != 2) {
       if (VEC == 2) {
@@ -1314,13 +1326,22 @@ struct KUpdate {
         old[0] = tgt[qi];
       }
     }
+    if (TGT == 3) {
+      if (VEC == 2) {
+        const double2_ o = *reinterpret_cast<const double2_*>(tgt2 + qi);
+        old2[0] = o.x, old2[VEC - 1] = o.y;
+      } else {
+        old2[0] = tgt2[qi];
+      }
+    }
     if (col < sy.NV) {
       const int g = col < sy.V0 ? 0 : (col - sy.V0) / sy.V / sy.S;
       const int b = sy.obs2blk[g];
       const double* lam = w.lampad + ((size_t)c * sy.Kmax + b) * RM;
+      const double* lam2 = w.lampad2 + ((size_t)c * sy.Kmax + b) * RM;
       const double* Jv = pick(sl.Jv, s) + (size_t)c * RM * sy.NV + col;
       CHMC_UNROLL
-      for (int k = 0; k < VEC; ++k) d[k] = 0.0;
+      for (int k = 0; k < VEC; ++k) d[k] = 0.0, d2[k] = 0.0;
       // observation row i of a block is structurally zero in the intervals after its own observation, and slots
       // beyond the block's row count are padding: only rows [m, nrows) are read
       const int m = col < sy.V0 ? 0 : g - sy.blk[b].obs0;
@@ -1332,14 +1353,20 @@ struct KUpdate {
             const double2_ jv = ld2_stream(Jv + (size_t)i * sy.NV);
             d[0] += jv.x * lam[i];
             d[VEC - 1] += jv.y * lam[i];
+            if (TGT == 3) d2[0] += jv.x * lam2[i], d2[VEC - 1] += jv.y * lam2[i];
           } else {
-            d[0] += Jv[(size_t)i * sy.NV] * lam[i];
+            const double jv = Jv[(size_t)i * sy.NV];
+            d[0] += jv * lam[i];
+            if (TGT == 3) d2[0] += jv * lam2[i];
           }
         }
       }
     } else {
       CHMC_UNROLL
-      for (int k = 0; k < VEC; ++k) d[k] = ncol_part(c, col + k);
+      for (int k = 0; k < VEC; ++k) {
+        d[k] = ncol_part(c, col + k);
+        if (TGT == 3) d2[k] = ncol_part2(c, col + k);
+      }
     }
     unsigned long long r = 0ULL;
     CHMC_UNROLL
@@ -1349,13 +1376,19 @@ struct KUpdate {
         r = vb > r ? vb : r;
       }
       old[k] = TGT == 2 ? d[k] : old[k] - d[k];
+      if (TGT == 3) old2[k] -= d2[k];
     }
     if (VEC == 2) {
       double2_ o;
       o.x = old[0], o.y = old[VEC - 1];
       *reinterpret_cast<double2_*>(tgt + qi) = o;
+      if (TGT == 3) {
+        o.x = old2[0], o.y = old2[VEC - 1];
+        *reinterpret_cast<double2_*>(tgt2 + qi) = o;
+      }
     } else {
       tgt[qi] = old[0];
+      if (TGT == 3) tgt2[qi] = old2[0];
     }
     return r;
   }
@@ -1500,7 +1533,7 @@ struct KJw {
     if (!w.ok[c]) return;
     const BlockDesc bd = sy.blk[b];
     const int s = sl.cur[c] ^ which;
-    const double* vct = (vsel == 0 ? pick(sl.p, s) : vsel == 1 ? w.pb : vsel == 2 ? w.vin : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
+    const double* vct = (vsel == 0 ? pick(sl.p, s) : vsel == 1 ? w.pb : vsel == 2 ? w.vin : vsel == 4 ? pick(sl.pg, s) : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
     const size_t cb = (size_t)c * sy.Kmax + b;
     double acc = 0.0;
     if (i < bd.nrows) {
@@ -1534,6 +1567,34 @@ struct KKick {
     const double g = pick(sl.grad, s)[tid] + (sy.gaussian ? 0.0 : pick(sl.q, s)[tid]);
     const double pin = pick(sl.p, s)[tid];
     (out_other ? pick(sl.p, s ^ 1) : pick(sl.p, s))[tid] = pin - h * g;
+  }
+};
+// pg = dh1_dpos of slot `which` (the kick direction of KKick), to be projected in place: P(q) dh1_dpos(q)
+struct KInitPg {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which;
+  CHMC_HD void operator()(int tid) const {
+    const int c = tid / sy.Q;
+    if (!w.ok[c]) return;
+    const int s = sl.cur[c] ^ which;
+    pick(sl.pg, s)[tid] = pick(sl.grad, s)[tid] + (sy.gaussian ? 0.0 : pick(sl.q, s)[tid]);
+  }
+};
+// A(h dt) for a momentum that is already tangent at the slot's point: P (p - h dh1_dpos) = p - h P dh1_dpos
+struct KKickPg {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which, out_other;
+  double hfrac;
+  CHMC_HD void operator()(int tid) const {
+    const int c = tid / sy.Q;
+    if (!w.ok[c]) return;
+    const int s = sl.cur[c] ^ which;
+    const double h = hfrac * w.dt[c];
+    (out_other ? pick(sl.p, s ^ 1) : pick(sl.p, s))[tid] = pick(sl.p, s)[tid] - h * pick(sl.pg, s)[tid];
   }
 };
 // h2_flow (:1222-1231) from slot `from` into (q_out, p_out): dst 0 = other slot, dst 1 = work (qb, pb)

@@ -362,7 +362,8 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
 // J w (lmult_by_jacob_constr :822-877): one wave per (chain, block); lanes stride over the block's columns
 // (unit-stride loads of the RM stored rows and of the vector), butterfly reduction, lane 0 adds the dc/du and
 // dc/dn terms.  Result in work.cpad.
-template <int RM>
+// TWO: a second vector (the slot's pg) shares the pass over the stored rows; its result goes to work.cpad2.
+template <int RM, bool TWO = false>
 __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int which, int vsel) {
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -372,13 +373,15 @@ __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int w
   if (!w.ok[c]) return;
   const BlockDesc bd = sy.blk[b];
   const int s = sl.cur[c] ^ which;
-  const double* vct = (vsel == 0 ? pick(sl.p, s) : vsel == 1 ? w.pb : vsel == 2 ? w.vin : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
+  const double* vct = (vsel == 0 ? pick(sl.p, s) : vsel == 1 ? w.pb : vsel == 2 ? w.vin : vsel == 4 ? pick(sl.pg, s) : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
+  const double* vct2 = pick(sl.pg, s) + (size_t)c * sy.Q;
   const size_t cb = (size_t)c * sy.Kmax + b;
   const double* Jv = pick(sl.Jv, s) + (size_t)c * RM * sy.NV + bd.col0;
   const double* wv = vct + sy.U + bd.col0;
-  double acc[RM];
+  const double* wv2 = vct2 + sy.U + bd.col0;
+  double acc[RM], acc2[RM];
 #pragma unroll
-  for (int i = 0; i < RM; ++i) acc[i] = 0.0;
+  for (int i = 0; i < RM; ++i) acc[i] = 0.0, acc2[i] = 0.0;
   // interval m of the block: only rows [m, nrows) are non-zero there (v_0 columns belong to interval 0)
   const int voff = bd.first ? sy.V0 : 0;
   const int per = sy.S * sy.V;
@@ -389,19 +392,26 @@ __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int w
     if (vec2) {
       for (int k = k0 + 2 * lane; k < k1; k += 128) {
         const double2_ x = *reinterpret_cast<const double2_*>(wv + k);
+        double2_ x2;
+        if (TWO) x2 = *reinterpret_cast<const double2_*>(wv2 + k);
 #pragma unroll
         for (int i = M0; i < RM; ++i)
           if (i < bd.nrows) {
             const double2_ j = *reinterpret_cast<const double2_*>(Jv + (size_t)i * sy.NV + k);
             acc[i] += j.x * x.x + j.y * x.y;
+            if (TWO) acc2[i] += j.x * x2.x + j.y * x2.y;
           }
       }
     } else {
       for (int k = k0 + lane; k < k1; k += 64) {
-        const double x = wv[k];
+        const double x = wv[k], x2 = TWO ? wv2[k] : 0.0;
 #pragma unroll
         for (int i = M0; i < RM; ++i)
-          if (i < bd.nrows) acc[i] += Jv[(size_t)i * sy.NV + k] * x;
+          if (i < bd.nrows) {
+            const double j = Jv[(size_t)i * sy.NV + k];
+            acc[i] += j * x;
+            if (TWO) acc2[i] += j * x2;
+          }
       }
     }
   };
@@ -425,21 +435,32 @@ __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int w
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     acc[i] = v;
+    if (TWO) {
+      v = acc2[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      acc2[i] = v;
+    }
   }
   if (lane < RM) {
     const int i = lane;
-    double a = 0.0;
+    double a = 0.0, a2 = 0.0;
 #pragma unroll
     for (int k = 0; k < RM; ++k)
-      if (k == i) a = acc[k];
+      if (k == i) a = acc[k], a2 = acc2[k];
     if (i < bd.nrows) {
       const double* ju = pick(sl.JuP, s) + (cb * RM + i) * sy.U;
       for (int d = 0; d < sy.U; ++d) a += ju[d] * vct[d];
       if (sy.noisy && i < bd.ny) a += sy.sigma * vct[sy.U + sy.NV + bd.obs0 + i];
+      if (TWO) {
+        for (int d = 0; d < sy.U; ++d) a2 += ju[d] * vct2[d];
+        if (sy.noisy && i < bd.ny) a2 += sy.sigma * vct2[sy.U + sy.NV + bd.obs0 + i];
+      }
     } else {
-      a = 0.0;
+      a = 0.0, a2 = 0.0;
     }
     w.cpad[cb * RM + i] = a;
+    if (TWO) w.cpad2[cb * RM + i] = a2;
   }
 }
 
@@ -1011,7 +1032,7 @@ __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work
       w.err[c] = bitsd(eb);
       w.ndq[c] = nb;
     } else if (TGT == 1) {
-      double* p = (psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
+      double* p = (psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : psel == 3 ? pick(sl.pg, s) : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
 #pragma unroll
       for (int a = 0; a < U; ++a) p[a] -= du[a];
     }

@@ -97,15 +97,17 @@ def check_ops_against_oracle(ctx, case, tol=1e-10):
     return worst
 
 
-def check_steps_against_oracle(ctx, case, dts, newton=True, n_steps=1, tol=1e-9, part=0):
+def check_steps_against_oracle(ctx, case, dts, newton=True, n_steps=1, tol=1e-9, part=0, project=True):
     """Fused leapfrog steps against the C oracle chain by chain, starting from chain 0's on-manifold state with
-    independent momenta."""
+    independent momenta (project=False: momenta that are NOT in the cotangent space, which the first half-kick of
+    the integrator has to project -- the library then cannot use its projected-gradient shortcut)."""
     osys, B = case["osys"], case["B"]
     rng = case["rng"]
     qq = np.repeat(case["q"][:1], B, 0)
     xx = np.repeat(case["x_obs"][:1], B, 0)
     ctx.set_state(qq, rng.standard_normal((B, ctx.Q)), xx, part)
-    ctx.project_onto_cotangent_space()
+    if project:
+        ctx.project_onto_cotangent_space()
     _, p0, _, _ = ctx.get_state()
     chains = []
     for c in range(B):

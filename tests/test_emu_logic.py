@@ -115,3 +115,13 @@ def test_init_by_linear_interpolation_matches_host(emu_lib, model, T, S, R, nois
     ctx.update_x_obs_seq()
     assert np.abs(ctx.get_state()[2] - xo).max() <= 1e-9 * (1.0 + np.abs(xo).max())
     ctx.close()
+
+
+
+def test_steps_from_unprojected_momentum(emu_lib):
+    """The integrator's first half-kick projects whatever momentum it is given (mici _step_a); a momentum set
+    without projection must take the full projection path, then the projected-gradient shortcut resumes."""
+    case = make_case("fhn", 6, 8, 2, True, B=4, seed=41)
+    ctx = make_ctx(case)
+    check_steps_against_oracle(ctx, case, np.array([0.05, -0.05, 0.1, 0.02]), newton=True, n_steps=3, project=False)
+    ctx.close()

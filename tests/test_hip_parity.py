@@ -253,3 +253,13 @@ def test_workload_device_init_equals_host_init():
     assert np.array_equal(xa, xb) and np.abs(qa - qb).max() <= 1e-11 * max(1.0, np.abs(qa).max())
     assert np.abs(a.ctx.hamiltonian() - b.ctx.hamiltonian()).max() <= 1e-7 * np.abs(a.ctx.hamiltonian()).max()
     a.ctx.close(), b.ctx.close()
+
+
+
+def test_steps_from_unprojected_momentum():
+    """The integrator's first half-kick projects whatever momentum it is given (mici _step_a); a momentum set
+    without projection must take the full projection path, then the projected-gradient shortcut resumes."""
+    case = make_case("fhn", 6, 8, 2, True, B=4, seed=41)
+    ctx = make_ctx(case)
+    check_steps_against_oracle(ctx, case, np.array([0.05, -0.05, 0.1, 0.02]), newton=True, n_steps=3, project=False)
+    ctx.close()
