@@ -1654,6 +1654,55 @@ struct KMomFix {
     pick(sl.p, s)[tid] = pn - sc * (flow - qn);
   }
 };
+// KMomFix and KInitPg of the new point in one pass (both only need the positions, the momentum and the gradient)
+struct KMomFixInitPg {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which;
+  CHMC_HD void operator()(int tid) const {
+    const int c = tid / sy.Q;
+    if (!w.ok[c]) return;
+    const int s = sl.cur[c] ^ which;
+    const double qp = pick(sl.q, s ^ 1)[tid], qn = pick(sl.q, s)[tid], pn = pick(sl.p, s)[tid];
+    double sc, flow;
+    if (sy.gaussian) {
+      sc = w.cdt[c] / w.sdt[c];
+      flow = (qp + w.sdt[c] * pn) / w.cdt[c];
+    } else {
+      sc = 1.0 / w.dt[c];
+      flow = qp + w.dt[c] * pn;
+    }
+    pick(sl.p, s)[tid] = pn - sc * (flow - qn);
+    pick(sl.pg, s)[tid] = pick(sl.grad, s)[tid] + (sy.gaussian ? 0.0 : qn);
+  }
+};
+// KKickPg into the other slot followed by KFlow from there, in one pass (tangent momentum at the start of a step)
+struct KKickFlowPg {
+  Sys sy;
+  Slots sl;
+  Work w;
+  double hfrac;
+  CHMC_HD void operator()(int tid) const {
+    const int c = tid / sy.Q;
+    if (!w.ok[c]) return;
+    const int s = sl.cur[c];
+    const double h = hfrac * w.dt[c];
+    const double q0 = pick(sl.q, s)[tid];
+    const double p0 = pick(sl.p, s)[tid] - h * pick(sl.pg, s)[tid];
+    double qn, pn;
+    if (sy.gaussian) {
+      const double sn = w.sdt[c], cs = w.cdt[c];
+      qn = q0 * cs + sn * p0;
+      pn = p0 * cs - sn * q0;
+    } else {
+      qn = q0 + w.dt[c] * p0;
+      pn = p0;
+    }
+    pick(sl.q, s ^ 1)[tid] = qn;
+    pick(sl.p, s ^ 1)[tid] = pn;
+  }
+};
 // reverse check distance max |q_back - q_start| (mici maximum_norm); column-max kernel, two components per work item
 struct KRevDiff {
   Sys sy;
