@@ -121,7 +121,12 @@ int chmc_project(chmc_ctx* ctx, int newton, const double* q, const double* dt, d
 
 /* One ConstrainedLeapfrogIntegrator.step per chain (mici 0.1.10, n_inner_step == 1): A(dt/2) B(dt) A(dt/2) with
  * forward projection, reverse projection and reversibility check.  dt [B] = state.dir * step_size; active [B]
- * (NULL: all).  A chain whose step fails keeps its state (Mici discards the partial step). */
+ * (NULL: all).  A chain whose step fails keeps its state (Mici discards the partial step).
+ * The two half-kicks A(dt/2): p <- P(q)[p - dt/2 dh1_dpos(q)] use the projected kick direction P(q) dh1_dpos(q) that
+ * the library keeps with every evaluated state: for a momentum already in the cotangent space (after
+ * chmc_sample_momentum, chmc_project_onto_cotangent_space or a previous step) P(q)[p - h g] = p - h P(q) g, which
+ * saves two of the three passes over the stored Jacobian rows; a momentum set through chmc_set_state /
+ * chmc_set_momentum(_device), or carried across chmc_switch_partition, takes the full projection as in the reference. */
 int chmc_leapfrog_step(chmc_ctx* ctx, const double* dt, const int* active, int n_inner_step, int newton,
                        double constraint_tol, double position_tol, double divergence_tol, int max_iters,
                        double reverse_check_tol, int* status, int* iters_fwd, int* iters_bwd, double* rev_err);
