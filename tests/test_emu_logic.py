@@ -125,3 +125,43 @@ def test_steps_from_unprojected_momentum(emu_lib):
     ctx = make_ctx(case)
     check_steps_against_oracle(ctx, case, np.array([0.05, -0.05, 0.1, 0.02]), newton=True, n_steps=3, project=False)
     ctx.close()
+
+
+
+def _status_case(emu_lib, ctx_kw, oracle_kw, expect):
+    from oracle import c_oracle
+    case = make_case("fhn", 6, 8, 2, True, B=3, seed=51)
+    ctx = make_ctx(case)
+    B = 3
+    qq = np.repeat(case["q"][:1], B, 0)
+    xx = np.repeat(case["x_obs"][:1], B, 0)
+    ctx.set_state(qq, case["rng"].standard_normal((B, ctx.Q)), xx, 0)
+    ctx.project_onto_cotangent_space()
+    q0, p0, _, _ = ctx.get_state()
+    dts = np.array([0.05, -0.08, 0.1])
+    res = ctx.leapfrog_step(dts, **ctx_kw)
+    q1, p1, _, _ = ctx.get_state()
+    for c in range(B):
+        ch = c_oracle.OracleChain(case["osys"])
+        ch.set(qq[c], p0[c], xx[c], 0)
+        st, itf, itb, rev = ch.step(dts[c], **oracle_kw)
+        assert res["status"][c] == st == expect, (c, res["status"][c], st)
+        assert np.array_equal(q1[c], q0[c]) and np.array_equal(p1[c], p0[c])  # a failed step leaves the state alone
+        if expect == 3:
+            assert res["iters_fwd"][c] == itf and 0 < res["rev_err"][c] < 1e-10 and 0 < rev < 1e-10  # both round-off
+    ctx.close()
+
+
+def test_status_diverged_matches_oracle(emu_lib):
+    """divergence_tol below the first constraint error: 'iteration diverged' (sde/mici_extensions.py:1393-1397)."""
+    _status_case(emu_lib, dict(divergence_tol=1e-12), dict(dtol=1e-12), 2)
+
+
+def test_status_not_converged_matches_oracle(emu_lib):
+    """max_iters too small: 'did not converge' (:1398-1402)."""
+    _status_case(emu_lib, dict(max_iters=1), dict(max_iters=1), 1)
+
+
+def test_status_non_reversible_matches_oracle(emu_lib):
+    """reverse_check_tol below the round-off of the forward-backward retraction: NonReversibleStepError (mici)."""
+    _status_case(emu_lib, dict(reverse_check_tol=1e-22), dict(rev_tol=1e-22), 3)
