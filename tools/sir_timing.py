@@ -1,5 +1,5 @@
 """Leapfrog steps per second for the SIR model at BASELINE.json config 4's shape (T = 14 observations, S = 200 steps,
-one block of R = 14 -> 16-row kernels), synthetic on-manifold states.  usage: python tools/sir_timing.py [chains] [S]"""
+one block of R = 14 -> 16-row kernels), synthetic on-manifold states.  usage: python tools/sir_timing.py [chains] [S] [R]"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -8,7 +8,8 @@ from manifold_mcmc_for_diffusions_amd.context import ChmcContext
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-T, R, sigma, dt_obs = 14, 14, 1.0, 0.25
+T, sigma, dt_obs = 14, 1.0, 0.25
+R = int(sys.argv[3]) if len(sys.argv) > 3 else 14
 m = em.MODELS["sir"]
 rng = np.random.default_rng(3)
 Q = m.dim_z + m.dim_v_0 + T * S * m.dim_v + T
