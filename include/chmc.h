@@ -20,6 +20,7 @@ extern "C" {
  * (sde/example_models/fhn.py, sde/example_models/sir.py) */
 #define CHMC_MODEL_FHN 0
 #define CHMC_MODEL_SIR 1
+#define CHMC_MODEL_FHN_NOTEBOOK 2 /* FitzHugh-Nagumo with the priors of FitzHugh-Nagumo_example.ipynb (cells 7-18) */
 
 /* per-chain status of a projection / leapfrog step (exception classes of the reference):
  *   0 ok

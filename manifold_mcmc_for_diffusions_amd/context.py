@@ -8,7 +8,7 @@ import numpy as np
 from . import _lib
 from ._lib import ChmcConfig, as_c, ptr, iptr, check
 
-MODEL_IDS = {"fhn": 0, "sir": 1}
+MODEL_IDS = {"fhn": 0, "sir": 1, "fhn_nb": 2}
 STATUS_NAMES = {0: "ok", 1: "not_converged", 2: "diverged", 3: "non_reversible", -1: "inactive"}
 
 

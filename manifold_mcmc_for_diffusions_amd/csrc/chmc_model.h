@@ -32,6 +32,32 @@ struct FhnModel {
   CHMC_HD static void obs_hess_vec(const double* x, const double* xd, double* o) { chmc_fhn_obs_hess_vec(x, xd, o); }
 };
 
+// FitzHugh-Nagumo with the priors of the reference's notebook (FitzHugh-Nagumo_example.ipynb cells 7-18): same
+// one-step map, different generate_z / generate_x_0.
+struct FhnNbModel {
+  static constexpr int ID = 2, X = CHMC_FHNNB_X, V = CHMC_FHNNB_V, Z = CHMC_FHNNB_Z, V0 = CHMC_FHNNB_V0, NK = CHMC_FHNNB_NK;
+  static constexpr int NXI = X + V + Z;
+  CHMC_HD static void precompute(const double* z, double dl, double* k) { chmc_fhnnb_precompute(z, dl, k); }
+  CHMC_HD static void step(const double* k, const double* x, const double* v, double* xn) { chmc_fhnnb_step(k, x, v, xn); }
+  CHMC_HD static void jac(const double* k, const double* x, const double* v, double* A, double* B, double* Zf) {
+    chmc_fhnnb_jac(k, x, v, A, B, Zf);
+  }
+  CHMC_HD static void jac_ab(const double* k, const double* x, const double* v, double* A, double* B) {
+    chmc_fhnnb_jac_ab(k, x, v, A, B);
+  }
+  CHMC_HD static void hess(const double* k, const double* x, const double* v, const double* S, double* out) {
+    chmc_fhnnb_step_hess(k, x, v, S, out);
+  }
+  CHMC_HD static void gz(const double* u, double* z) { chmc_fhnnb_gz(u, z); }
+  CHMC_HD static void gz_jac(const double* u, double* G) { chmc_fhnnb_gz_jac(u, G); }
+  CHMC_HD static void gz_hess(const double* u, const double* ud, const double* zb, double* o) { chmc_fhnnb_gz_hess(u, ud, zb, o); }
+  CHMC_HD static void gx0(const double* z, const double* v0, double* x0) { chmc_fhnnb_gx0(z, v0, x0); }
+  CHMC_HD static void gx0_jac(double* dz, double* dv0) { chmc_fhnnb_gx0_jac(dz, dv0); }
+  CHMC_HD static double obs(const double* x) { return chmc_fhnnb_obs(x); }
+  CHMC_HD static void obs_grad(const double* x, double* g) { chmc_fhnnb_obs_grad(x, g); }
+  CHMC_HD static void obs_hess_vec(const double* x, const double* xd, double* o) { chmc_fhnnb_obs_hess_vec(x, xd, o); }
+};
+
 // SIR in (log S, log I, log-contact-rate) coordinates.  The first two components are clipped
 // below at -500 before a step and a clipped component keeps its (clipped) value
 // (sde/example_models/sir.py:54-70); derivatives through a clipped component are zero.

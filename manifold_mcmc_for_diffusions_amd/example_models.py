@@ -67,6 +67,22 @@ class _Fhn:
         return x_seq[..., 0:1]
 
 
+class _FhnNb(_Fhn):
+    """FitzHugh-Nagumo as set up in the reference's notebook (FitzHugh-Nagumo_example.ipynb cells 7-18): the same
+    drift, diffusion and strong-order-1.5 step, with the notebook's priors."""
+    name, model_id = "fhn_nb", 2
+
+    @staticmethod
+    def _generate_z(u):
+        u = np.asarray(u)
+        return np.stack([np.exp(0.5 * u[..., 0] - 1), np.exp(0.5 * u[..., 1] - 2), 0.5 * u[..., 2] + 1,
+                         0.5 * u[..., 3] + 1], -1)
+
+    @staticmethod
+    def _generate_x_0(z, v_0):
+        return np.asarray(v_0, dtype=np.float64) - 0.5
+
+
 class _Sir:
     name, model_id = "sir", 1
     dim_x, dim_y, dim_w, dim_z, dim_v_0, dim_v = 3, 1, 3, 4, 1, 3
@@ -133,8 +149,9 @@ def _finish(cls):
 
 
 fhn = _finish(_Fhn)
+fhn_nb = _finish(_FhnNb)
 sir = _finish(_Sir)
-MODELS = {"fhn": fhn, "sir": sir}
+MODELS = {"fhn": fhn, "sir": sir, "fhn_nb": fhn_nb}
 
 
 def generate_x_seq(model, z, x_0, v_seq, δ):

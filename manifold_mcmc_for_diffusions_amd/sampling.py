@@ -48,7 +48,8 @@ def _mean_over_all_chains(local_sum, local_count):
 
 
 def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_adapt=0, solver=None, rng=None,
-                       n_head=6, callback=None, trace_dir=None, trace_func=None, total_chains=None):
+                       n_head=6, callback=None, trace_dir=None, trace_func=None, total_chains=None,
+                       jitter_length=False):
     """Runs n_iter transitions on all chains of `ctx`; returns traces of the first `n_head` position components
     ([n_iter, B, n_head]), accept statistics and the step size used.  Directions are sampled per chain and
     transition (forward / backward in time), failed trajectories are rejected.
@@ -58,7 +59,11 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
     head components as `pos_head` and `hamiltonian`).  Under torch.distributed the accept statistic that drives the
     step-size adaptation is averaged over the chains of all ranks; with `total_chains` (the number of chains of the
     whole job) the per-chain directions and accept draws are taken from one stream indexed by the global chain
-    number, so that any sharding of the chains reproduces the single-process run."""
+    number, so that any sharding of the chains reproduces the single-process run.
+    jitter_length: every chain draws its number of leapfrog steps uniformly from 1..n_step per transition (a mixture
+    of reversible kernels, so still a valid sampler); chains in regions where the retraction often fails then still
+    move with their short trajectories instead of rejecting every long one (Mici's dynamic transition gets the same
+    effect by ending a trajectory at the failing step)."""
     solver = dict(newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10, max_iters=50,
                   reverse_check_tol=2e-8) if solver is None else solver
     rng = np.random.default_rng(seed) if rng is None else rng
@@ -70,6 +75,7 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
             return rng.random(B)
         return rng.random(total_chains)[chain_offset:chain_offset + B]
 
+    stuck = np.zeros(B, dtype=np.int64)  # consecutive trajectories with zero acceptance probability
     heads = np.empty((n_iter, B, n_head))
     acc_hist, eps_hist, fail_hist = np.empty(n_iter), np.empty(n_iter), np.empty(n_iter)
     if trace_func is None:
@@ -84,15 +90,24 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
         ctx.sample_momentum(seed, it + 1, chain_offset)
         h0 = ctx.hamiltonian()[:, 0]
         ctx.snapshot()
-        dt = np.where(draw() < 0.5, step_size, -step_size)
+        # warm-up only: a chain whose trajectories keep failing (a start far from the typical set, where the shared
+        # step size is too long for the retraction) backs its own step size off until it moves again
+        scale = 0.5 ** np.minimum(stuck, 8) if it < n_adapt else 1.0
+        dt = np.where(draw() < 0.5, step_size, -step_size) * scale
         act = np.ones(B, dtype=np.int32)
-        for _ in range(n_step):
-            r = ctx.leapfrog_step(dt, active=act, **solver)
-            act &= (r["status"] == 0).astype(np.int32)
+        length = 1 + np.floor(draw() * n_step).astype(np.int64) if jitter_length else np.full(B, n_step)
+        for k in range(n_step):
+            run = (act == 1) & (k < length)
+            if not run.any():
+                break
+            r = ctx.leapfrog_step(dt, active=run.astype(np.int32), **solver)
+            bad = run & (r["status"] != 0)
+            act &= (~bad).astype(np.int32)
         h1 = ctx.hamiltonian()[:, 0]
         dh = h1 - h0
         prob = np.where((act == 1) & np.isfinite(dh), np.exp(np.minimum(0.0, -np.where(np.isfinite(dh), dh, np.inf))), 0.0)
         accept = draw() < prob
+        stuck = np.where(prob > 0.0, 0, stuck + 1)
         ctx.restore((~accept).astype(np.int32))
         ctx.switch_partition()
         heads[it] = ctx.get_head(n_head)

@@ -73,7 +73,7 @@ def _c(a):
     return np.ascontiguousarray(a, dtype=np.float64)
 
 
-MODEL_IDS = {"fhn": 0, "sir": 1}
+MODEL_IDS = {"fhn": 0, "sir": 1, "fhn_nb": 2}
 
 
 class OracleSystem:
@@ -96,7 +96,7 @@ class OracleSystem:
         self.num_partition = L.orc_num_partition(self.h)
         self.rmax = L.orc_rmax(self.h)
         self.NV = L.orc_dim_nv(self.h)
-        self.X = {"fhn": 2, "sir": 3}[model]
+        self.X = {"fhn": 2, "sir": 3, "fhn_nb": 2}[model]
         self.U = 4
 
     def __del__(self):

@@ -7,15 +7,16 @@ from manifold_mcmc_for_diffusions_amd import example_models as em
 
 FHN_U = np.array([-1.2, -2.0, 0.4, 0.8])  # log sigma, log eps, log gamma, beta  (sigma 0.3, eps 0.135, gamma 1.5)
 SIR_U = np.array([-1.0, -1.0, 1.0, 0.0])
+FHN_NB_U = np.array([-0.4, -0.0, 1.0, -0.4])  # notebook priors: sigma 0.30, eps 0.135, gamma 1.5, beta 0.8
 
 
 def random_q(model, T, S, noisy, B, rng, v_scale=0.3, u_scale=0.1):
     m = em.MODELS[model]
     Q = m.dim_z + m.dim_v_0 + T * S * m.dim_v + (T if noisy else 0)
     q = np.zeros((B, Q))
-    u0 = FHN_U if model == "fhn" else SIR_U
+    u0 = FHN_U if model == "fhn" else FHN_NB_U if model == "fhn_nb" else SIR_U
     q[:, :4] = u_scale * rng.standard_normal((B, 4)) + u0
-    if model == "fhn":
+    if model in ("fhn", "fhn_nb"):
         q[:, 4:6] = 0.5 * rng.standard_normal((B, 2))
     else:
         q[:, 4:5] = 1.0 + 0.1 * rng.standard_normal((B, 1))
@@ -33,8 +34,8 @@ def make_case(model, T, S, R, noisy, B, seed, obs_interval=None, gaussian=False)
     rng = np.random.default_rng(seed)
     m = em.MODELS[model]
     if obs_interval is None:
-        obs_interval = 0.2 if model == "fhn" else 0.25
-    sigma = (0.1 if model == "fhn" else 1.0) if noisy else None
+        obs_interval = 0.2 if model in ("fhn", "fhn_nb") else 0.25
+    sigma = (0.1 if model in ("fhn", "fhn_nb") else 1.0) if noisy else None
     q = random_q(model, T, S, noisy, B, rng)
     tmp = c_oracle.OracleSystem(model, obs_interval, S, R, np.zeros(T), sigma=sigma, use_gaussian_splitting=gaussian)
     xo = np.stack([tmp.generate_x_obs_seq(q[c]) for c in range(B)])

@@ -38,6 +38,8 @@ CASES = [
     ("sir", 5, 6, None, True, False),
     ("sir", 6, 8, 2, True, False),
     ("sir", 14, 6, 14, True, False),
+    ("fhn_nb", 7, 5, 3, False, True),  # the notebook's model: noiseless observations, Gaussian splitting
+    ("fhn_nb", 6, 4, 2, True, False),
 ]
 
 

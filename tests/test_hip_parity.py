@@ -21,6 +21,8 @@ SMALL = [
     ("sir", 5, 6, None, True, False),
     ("sir", 6, 8, 2, True, False),
     ("sir", 14, 6, 14, True, False),
+    ("fhn_nb", 7, 5, 3, False, True),  # the notebook's model: noiseless observations, Gaussian splitting
+    ("fhn_nb", 6, 4, 2, True, False),
 ]
 
 
@@ -160,6 +162,7 @@ SCAN = [
     ("fhn", 6, 8, 2, True, True),
     ("sir", 14, 8, 14, True, False),
     ("sir", 6, 16, 2, True, False),
+    ("fhn_nb", 7, 8, 3, False, True),
 ]
 
 

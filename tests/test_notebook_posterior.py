@@ -1,0 +1,36 @@
+"""Statistical pin against the reference's only known-answer material for this path: the posterior table printed by
+FitzHugh-Nagumo_example.ipynb (tests/golden/reference_data/notebook_posterior_table.json).  The notebook's experiment
+is re-run on the GPU (same data from the same legacy seed, same model, priors, discretisation, splitting, solver and
+tolerances; a static-trajectory sampler instead of Mici's dynamic one, 64 chains instead of 2) and the posterior means
+must agree within Monte-Carlo error, the posterior standard deviations within 25 %."""
+import os
+import sys
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_data_regenerated_from_the_notebook_seed():
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import fhn_notebook_posterior as nb
+    d = nb.notebook_data()
+    np.testing.assert_allclose(d["q_ref"][:3], [1.62073967, 1.08346121, 0.67204724], atol=5e-9)
+    assert d["y"].shape == (100,) and np.isfinite(d["y"]).all()
+    # data-generating parameters of the notebook's corner plot truths: generate_z(q_ref[:4])
+    np.testing.assert_allclose(d["z_ref"], [np.exp(0.5 * d["q_ref"][0] - 1), np.exp(0.5 * d["q_ref"][1] - 2),
+                                            0.5 * d["q_ref"][2] + 1, 0.5 * d["q_ref"][3] + 1])
+
+
+@pytest.mark.timeout(900)
+def test_posterior_matches_the_notebook_table(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import fhn_notebook_posterior as nb
+    rows, res, n_moving = nb.run(64, 700, 200, 24, out_dir=str(tmp_path / "run"), verbose=False)
+    assert n_moving >= 58                               # at most a few stuck starts
+    assert 0.6 < res["accept_stat"][200:].mean() < 0.95
+    for r in rows:
+        assert abs(r["z"]) < 4.0, r                     # means agree within Monte-Carlo error
+        assert 0.75 < r["sd"] / r["ref_sd"] < 1.25, r   # posterior spread agrees
+        assert r["r_hat"] < 1.1, r

@@ -212,6 +212,20 @@ def model_fhn():
                 gx0=gx0, obs=obs)
 
 
+def model_fhn_nb():
+    """FitzHugh-Nagumo with the priors of the reference's notebook (FitzHugh-Nagumo_example.ipynb, cells 7-18): the
+    same drift / diffusion / integrator as model_fhn, sigma = exp(u0/2 - 1), eps = exp(u1/2 - 2), gamma = u2/2 + 1,
+    beta = u3/2 + 1, x_0 = (-1/2, -1/2) + v_0.  Used to reproduce the notebook's posterior table (its only
+    known-answer material)."""
+    m = model_fhn()
+    u, v0 = m["u"], m["v0"]
+    h = sp.Rational(1, 2)
+    m["name"] = "fhnnb"
+    m["gz"] = [sp.exp(h * u[0] - 1), sp.exp(h * u[1] - 2), h * u[2] + 1, h * u[3] + 1]
+    m["gx0"] = [v0[0] - h, v0[1] - h]
+    return m
+
+
 def model_sir():
     X, V, Z, U, V0 = 3, 3, 4, 4, 1
     y = sp.symbols("x0:3", real=True)
@@ -416,7 +430,7 @@ HEADER = """/* GENERATED by tools/gen_models.py -- do not edit.
 
 def main():
     parts = [HEADER]
-    for mk in (model_fhn, model_sir):
+    for mk in (model_fhn, model_fhn_nb, model_sir):
         m = mk()
         print("model", m["name"], file=sys.stderr)
         for i, e in enumerate(m["f"]):
