@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int w
 template <class M, int RM>
 __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, int which) {
   constexpr int X = M::X, V = M::V, Z = M::Z, V0 = M::V0;
-  constexpr int URM = RM <= 8 ? 64 : 1;  // 16-row instantiation: keep the row loops rolled (register file)
+  constexpr int URM = 64;  // (the forward sweep is correct fully unrolled at 16 rows as well; the backward sweep is not, see there)
   __shared__ double sm[4][RM * RM + RM * Z];
   const int lane = threadIdx.x & 63;
   const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
