@@ -89,6 +89,7 @@ struct Work {
   double* vin;      // [B][Q]        generic input vector (per-op API)
   double* Xd;       // [B][T*S][RM][X] tangents for grad log det
   double* gup;      // [B][Kmax][U]
+  double* JvW;      // [B][RM][NV]   rows of the current Newton iterate (16-row blocks only: Gram formed by k_gram_rows)
   double* Dw;       // [B][Kmax][RM][RM] Gram block of the current evaluation (wave kernels -> factor kernels)
   double* JuL;      // [B][Kmax][RM][U]  dc/du rows of the current Newton iterate
   double* zbP;      // [B][Kmax][RM][Z]  dc/dz rows (before the generate_z chain rule) of the last state evaluation

@@ -62,12 +62,16 @@ __device__ inline void matmul_xx(const double* a, const double* b, double* c) { 
 
 // MODE 0: state evaluation -- store dc/dv rows, symmetric Gram, dc/du rows into the slot.
 // MODE 1: Newton iteration -- Gram of the iterate's rows against the stored rows of slot `which`.
-template <class M, int RM, int MODE>
+// GRAM false (16-row blocks): no Gram accumulation -- the rows are stored (MODE 0: into the slot, MODE 1: into
+// work.JvW) and k_gram_rows forms the Gram block from the stored rows.  A 16 x 16 accumulator per lane does not fit
+// the register file: with it the sweep ran out of scratch memory, 25x slower than the 8-row instantiations.
+template <class M, int RM, int MODE, bool GRAM = true>
 __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int which, int qsel) {
   constexpr int X = M::X, V = M::V, Z = M::Z, U = M::Z, V0 = M::V0;
-  // the fully unrolled 16-row instantiation is mis-compiled by ROCm 7.2 under heavy register spilling (wrong dc/du);
-  // it keeps its row loops rolled, the <= 8-row instantiations are fully unrolled
-  constexpr int URM = RM <= 8 ? 64 : 1;
+  // the fully unrolled 16-row instantiation WITH the Gram accumulator is mis-compiled by ROCm 7.2 under heavy register
+  // spilling (wrong dc/du) and keeps its row loops rolled; everything else is fully unrolled
+  constexpr int URM = (RM <= 8 || !GRAM) ? 64 : 1;
+  constexpr bool STORE_ROWS = MODE == 0 || !GRAM;
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= sy.B * sy.K) return;
@@ -81,17 +85,17 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   const double* q = (MODE == 1 ? (qsel ? w.qb : pick(sl.q, sl_ ^ 1)) : pick(sl.q, sl_)) + (size_t)c * sy.Q;
   const double* traj = (MODE == 1 ? w.trajw : pick(sl.traj, sl_)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
   const double* Jr = pick(sl.Jv, sl_) + (size_t)c * RM * NV;  // MODE 1: read; MODE 0: written through Jo
-  double* Jo = pick(sl.Jv, sl_) + (size_t)c * RM * NV;
+  double* Jo = (MODE == 1 ? w.JvW : pick(sl.Jv, sl_)) + (size_t)c * RM * NV;
   ChainConsts<M> cc;
   cc.init(q, sy.dl);
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
   const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
 
-  double Lam[RM * X], Dacc[RM * RM], zacc[RM * Z];
+  double Lam[RM * X], Dacc[GRAM ? RM * RM : 1], zacc[RM * Z];
 #pragma unroll URM
   for (int i = 0; i < RM * X; ++i) Lam[i] = 0.0;
 #pragma unroll
-  for (int i = 0; i < RM * RM; ++i) Dacc[i] = 0.0;
+  for (int i = 0; i < (GRAM ? RM * RM : 1); ++i) Dacc[i] = 0.0;
 #pragma unroll URM
   for (int i = 0; i < RM * Z; ++i) zacc[i] = 0.0;
 
@@ -122,7 +126,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
       for (int a = 0; a < X; ++a) r.x[a] = ld_stream(traj + (size_t)r.s * X + a);
 #pragma unroll
       for (int a = 0; a < V; ++a) r.v[a] = vbase[(size_t)r.s * V + a];
-      if (MODE == 1) {
+      if (MODE == 1 && GRAM) {
         const size_t col = colb + (size_t)r.s * V;
 #pragma unroll URM
         for (int i = 0; i < RM; ++i)  // (skipping the structurally zero rows here breaks the load pipelining: 2x slower)
@@ -134,7 +138,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
       for (int a = 0; a < X; ++a) r.x[a] = 0.0;
 #pragma unroll
       for (int a = 0; a < V; ++a) r.v[a] = 0.0;
-      if (MODE == 1) {
+      if (MODE == 1 && GRAM) {
 #pragma unroll URM
         for (int i = 0; i < RM * V; ++i) r.jp[i] = 0.0;
       }
@@ -201,7 +205,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
       }
     }
     const size_t col = colb + (size_t)r.s * V;
-    if (MODE == 0) {
+    if (STORE_ROWS) {
       if (r.valid) {
 #pragma unroll URM
         for (int i = 0; i < RM; ++i) {
@@ -213,6 +217,10 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
           }
         }
       }
+    }
+    if (!GRAM) {
+      // (Gram block formed afterwards by k_gram_rows)
+    } else if (MODE == 0) {
 #pragma unroll URM
       for (int i = 0; i < RM; ++i)
 #pragma unroll URM
@@ -298,9 +306,12 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
         zacc[i * Z + mz] += tt;
       }
     }
-    if (MODE == 0) {
+    if (STORE_ROWS) {
       for (int i = 0; i < RM; ++i)
         for (int d = 0; d < V0; ++d) Jo[(size_t)i * NV + d] = j0[i * V0 + d];
+    }
+    if (!GRAM) {
+    } else if (MODE == 0) {
       for (int i = 0; i < RM; ++i)
         for (int jj = 0; jj <= i; ++jj)
           for (int d = 0; d < V0; ++d) Dacc[i * RM + jj] += j0[i * V0 + d] * j0[jj * V0 + d];
@@ -312,7 +323,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   }
   // combine the per-lane partial sums over the wave
 #pragma unroll
-  for (int i = 0; i < RM * RM; ++i) {
+  for (int i = 0; i < (GRAM ? RM * RM : 0); ++i) {
     if (MODE == 0 && (i % RM) > (i / RM)) continue;
     double v = Dacc[i];
 #pragma unroll
@@ -327,21 +338,23 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
     zacc[i] = v;
   }
   if (lane == 0) {
-    if (MODE == 0) {
+    if (GRAM) {
+      if (MODE == 0) {
 #pragma unroll URM
-      for (int i = 0; i < RM; ++i)
+        for (int i = 0; i < RM; ++i)
 #pragma unroll URM
-        for (int jj = 0; jj < i; ++jj) Dacc[jj * RM + i] = Dacc[i * RM + jj];
-    }
-    const double s2 = sy.sigma * sy.sigma;
+          for (int jj = 0; jj < i; ++jj) Dacc[jj * RM + i] = Dacc[i * RM + jj];
+      }
+      const double s2 = sy.sigma * sy.sigma;
 #pragma unroll URM
-    for (int i = 0; i < RM; ++i) {
-      if (sy.noisy && i < bd.ny) Dacc[i * RM + i] += s2;  // dc/dn dc/dn^T (:772-791)
-      if (i >= bd.nrows) Dacc[i * RM + i] = 1.0;          // identity padding
-    }
-    double* Do = w.Dw + cb * RM * RM;
+      for (int i = 0; i < RM; ++i) {
+        if (sy.noisy && i < bd.ny) Dacc[i * RM + i] += s2;  // dc/dn dc/dn^T (:772-791)
+        if (i >= bd.nrows) Dacc[i * RM + i] = 1.0;          // identity padding
+      }
+      double* Do = w.Dw + cb * RM * RM;
 #pragma unroll
-    for (int i = 0; i < RM * RM; ++i) Do[i] = Dacc[i];
+      for (int i = 0; i < RM * RM; ++i) Do[i] = Dacc[i];
+    }
     if (MODE == 0) {
       double* zo = w.zbP + cb * RM * Z;
 #pragma unroll URM
@@ -356,6 +369,65 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
         for (int mz = 0; mz < Z; ++mz) tt += zacc[i * Z + mz] * G[mz * Z + d];
         ju[i * U + d] = tt;
       }
+  }
+}
+
+// Gram block of a (chain, block) from stored rows (16-row blocks, see k_rev_wave<.., GRAM = false>):
+//   D = Ja Jb^T + sigma^2 on the observation rows + identity padding      (compute_D_blocks :765-792, :742-744)
+// Ja: rows of the iterate (work.JvW) or of the slot itself, Jb: stored rows of slot `which`.  One wavefront per
+// (chain, block, group of NRG rows): NRG x RM accumulators per lane, lanes stride over the block's columns.
+template <int RM, int NRG>
+__global__ void __launch_bounds__(256) k_gram_rows(Sys sy, Slots sl, Work w, int which, int newton) {
+  constexpr int NG = RM / NRG;
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wid >= sy.B * sy.K * NG) return;
+  const int g = wid % NG;
+  const int cbi = sy.order[wid / NG];
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (newton ? !w.nw[c] : !w.ok[c]) return;
+  const BlockDesc bd = sy.blk[b];
+  const int s = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const double* Jb = pick(sl.Jv, s) + (size_t)c * RM * sy.NV + bd.col0;
+  const double* Ja = (newton ? w.JvW : pick(sl.Jv, s)) + (size_t)c * RM * sy.NV + bd.col0 + (size_t)g * NRG * sy.NV;
+  double acc[NRG * RM];
+#pragma unroll
+  for (int i = 0; i < NRG * RM; ++i) acc[i] = 0.0;
+  for (int k = lane; k < bd.ncols; k += 64) {
+    double a[NRG], bb[RM];
+#pragma unroll
+    for (int i = 0; i < NRG; ++i) a[i] = Ja[(size_t)i * sy.NV + k];
+#pragma unroll
+    for (int j = 0; j < RM; ++j) bb[j] = Jb[(size_t)j * sy.NV + k];
+#pragma unroll
+    for (int i = 0; i < NRG; ++i)
+#pragma unroll
+      for (int j = 0; j < RM; ++j) acc[i * RM + j] += a[i] * bb[j];
+  }
+#pragma unroll
+  for (int i = 0; i < NRG * RM; ++i) {
+    double v = acc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    acc[i] = v;
+  }
+  if (lane == 0) {
+    const double s2 = sy.sigma * sy.sigma;
+    double* Do = w.Dw + cb * RM * RM + (size_t)g * NRG * RM;
+#pragma unroll
+    for (int i = 0; i < NRG; ++i) {
+      const int gi = g * NRG + i;
+#pragma unroll
+      for (int j = 0; j < RM; ++j) {
+        double v = acc[i * RM + j];
+        if (gi == j) {
+          if (sy.noisy && gi < bd.ny) v += s2;
+          if (gi >= bd.nrows) v = 1.0;
+        }
+        Do[i * RM + j] = v;
+      }
+    }
   }
 }
 
