@@ -98,3 +98,25 @@ def test_rhat_and_ess_on_known_processes():
     assert split_rhat_and_ess(shifted)[0] > 1.5
     s = summarize({"a": iid, "b": np.stack([iid, ar[:, :2000]], -1)})
     assert set(s["mean"]) == {"a", "b[0]", "b[1]"}
+
+
+def test_jittered_lengths_and_warmup_backoff(emu_lib):  # noqa: F811
+    """jitter_length draws every chain's number of steps per transition; chains that cannot move back their step
+    size off during warm-up only.  Every retained state stays on the manifold and the run is reproducible."""
+    from manifold_mcmc_for_diffusions_amd.sampling import sample_static_chmc
+    from manifold_mcmc_for_diffusions_amd import example_models as em
+    from manifold_mcmc_for_diffusions_amd.init import fhn_initial_states
+    from manifold_mcmc_for_diffusions_amd.context import ChmcContext
+    y = em.simulate_fhn_observations(6, 0.2, 50, seed=5, sigma=0.1)
+    outs = []
+    for _ in range(2):
+        ctx = ChmcContext("fhn", 0.2, 4, 2, y[:, 0], sigma=0.1, num_chains=4)
+        q, xo, _ = fhn_initial_states(em.fhn, 0.2, 4, y, 4, True, seed=7)
+        ctx.set_state(q, None, xo, 0)
+        calls0 = ctx.counters()["leapfrog_step"]
+        res = sample_static_chmc(ctx, 10, 6, 0.05, seed=3, n_adapt=5, jitter_length=True)
+        assert ctx.counters()["leapfrog_step"] - calls0 <= 10 * 6  # chains stop after their own length
+        assert np.abs(ctx.constr()).max() < 1e-8 and np.isfinite(res["heads"]).all()
+        outs.append(res["heads"])
+        ctx.close()
+    np.testing.assert_array_equal(outs[0], outs[1])
