@@ -78,3 +78,80 @@ def fhn_initial_states_device(ctx, model, y_seq, seed=20200710, chain_offset=0, 
     us, v0s, xos, rngs = fhn_initial_draws(model, y_seq, ctx.B, seed, chain_offset, total_chains)
     ctx.init_by_linear_interpolation(us, v0s, xos, partition)
     return rngs
+
+
+def find_initial_states_by_gradient_descent_noisy_system(ctx, rng, adam_step_size=2e-2, max_iters=1000, max_init_tries=100,
+                                                         threshold=1.0, slow_progress_ratio=0.8, check_iter=100,
+                                                         max_num_tries=10, log=None):
+    """find_initial_state_by_gradient_descent_noisy_system (sde/mici_extensions.py:1679-1801), for every chain of `ctx`
+    at once (the SIR script's initialisation, scripts/sir_model_chmc_experiment.py:103-109).
+
+    Adam descent on the negative log posterior density of the noisy-observation model in (u, v_0, v_seq),
+        1/2 sum_t r_t^2 + 1/2 |u_v|^2,   r_t = (y_t - obs_func(x_t(u_v))) / sigma          (fixed sigma: log sigma constant),
+    until the mean squared residual drops below `threshold`; the point is then put on the manifold by setting the
+    observation-noise components to the residuals (:1767-1775).  The residuals and their gradient come from the
+    library: `ctx` must hold the whole observation sequence in ONE sub-sequence (num_obs_per_subseq >= num_obs, i.e.
+    K = 1, the SIR configuration), where the constraint function at n = 0 is obs_func(x_t) - y_t for the full scan and
+    J^T lambda is its exact adjoint.  Chains restart from a fresh draw when Adam diverges or stalls, as in the reference.
+    Leaves the found states set on `ctx` (zero momentum) and returns (q [B, Q], x_obs_seq [B, T, X], tries [B])."""
+    if not ctx.noisy or ctx.num_blocks != 1 or ctx.num_partition != 1:
+        raise ValueError("needs a noisy-observation context with a single sub-sequence (num_obs_per_subseq >= num_obs)")
+    B, Q, T = ctx.B, ctx.Q, ctx.T
+    nuv = Q - T
+    sigma = float(ctx.sigma)
+    xo0 = np.zeros((B, T, ctx.X))
+
+    def residuals_and_grad(u_v):
+        q = np.concatenate([u_v, np.zeros((B, T))], 1)
+        ctx.set_state(q, None, xo0, 0)
+        c = ctx.constr()                                   # obs_func(x_t) - y_t
+        g = ctx.rmult_by_jacob_constr(c / sigma ** 2)[:, :nuv] + u_v
+        return -c / sigma, g
+
+    u_v = rng.standard_normal((B, nuv))
+    m, v = np.zeros_like(u_v), np.zeros_like(u_v)
+    t_adam = np.zeros(B)
+    done = np.zeros(B, dtype=bool)
+    tries = np.ones(B, dtype=np.int64)
+    prev = np.full(B, np.inf)
+    it_in_try = np.zeros(B, dtype=np.int64)
+    res_found = np.zeros((B, T))
+    b1, b2, eps = 0.9, 0.999, 1e-8                         # jax.example_libraries.optimizers.adam defaults
+    for _ in range(max_iters * max_num_tries):
+        r, g = residuals_and_grad(u_v)
+        msq = np.mean(r ** 2, 1)
+        newly = ~done & np.isfinite(msq) & (msq < threshold)
+        res_found[newly] = r[newly]
+        done |= newly
+        if done.all():
+            break
+        stalled = (it_in_try % check_iter == 0) & (it_in_try > 0) & (it_in_try < max_iters // 2) & (
+            msq / prev > slow_progress_ratio)
+        restart = ~done & (~np.isfinite(msq) | ~np.isfinite(g).all(1) | stalled | (it_in_try >= max_iters))
+        upd = (it_in_try % check_iter == 0) & ~restart
+        prev = np.where(upd, msq, prev)
+        if restart.any():
+            if (tries[restart] >= max_num_tries * max_init_tries).any():
+                raise RuntimeError(f"Did not find valid state in {max_num_tries} tries.")
+            n = int(restart.sum())
+            u_v[restart] = rng.standard_normal((n, nuv))
+            m[restart], v[restart], t_adam[restart], it_in_try[restart], prev[restart] = 0.0, 0.0, 0.0, 0, np.inf
+            tries[restart] += 1
+        step = ~done & ~restart
+        t_adam[step] += 1
+        m[step] = b1 * m[step] + (1 - b1) * g[step]
+        v[step] = b2 * v[step] + (1 - b2) * g[step] ** 2
+        mh = m[step] / (1 - b1 ** t_adam[step])[:, None]
+        vh = v[step] / (1 - b2 ** t_adam[step])[:, None]
+        u_v[step] -= adam_step_size * mh / (np.sqrt(vh) + eps)
+        it_in_try[step] += 1
+        if log is not None and int(it_in_try.max()) % check_iter == 0:
+            log(f"  adam: {int(done.sum())} of {B} chains below the threshold, median mean r^2 {np.median(msq):.3g}")
+    else:
+        raise RuntimeError("Did not find valid states within the iteration budget.")
+    q = np.concatenate([u_v, res_found], 1)                # n := residuals puts the point on the manifold
+    ctx.set_state(q, None, xo0, 0)
+    ctx.update_x_obs_seq()
+    xo = ctx.get_state(want_p=False)[2]
+    ctx.set_state(q, None, xo, 0)
+    return q, xo, tries

@@ -306,3 +306,41 @@ def test_status_not_converged_matches_oracle():
 def test_status_non_reversible_matches_oracle():
     """reverse_check_tol below the round-off of the forward-backward retraction: NonReversibleStepError (mici)."""
     _status_case(dict(reverse_check_tol=1e-22), dict(rev_tol=1e-22), 3)
+
+
+def test_sir_initial_states_by_gradient_descent():
+    """The SIR script's initialisation (find_initial_state_by_gradient_descent_noisy_system, :1679-1801), batched on
+    top of the library's constraint / adjoint operators: found states lie on the manifold, the residuals became the
+    observation-noise components, and the gradient used by Adam agrees with finite differences."""
+    from manifold_mcmc_for_diffusions_amd import example_models as em, init
+    from manifold_mcmc_for_diffusions_amd.context import ChmcContext
+    T, S, B = 6, 8, 5
+    rng = np.random.default_rng(3)
+    y = np.array([3.0, 8.0, 28.0, 75.0, 120.0, 170.0])  # infection counts rising as in the boarding-school data
+    ctx = ChmcContext("sir", 1.0, S, T, y, sigma=1.0, num_chains=B)
+    assert ctx.num_blocks == 1
+    # gradient check of the objective at a random point
+    u_v = 0.3 * rng.standard_normal((B, ctx.Q - T))
+    u_v[:, :4] += np.array([-1.0, -1.0, 1.0, 0.0])
+
+    def objective(uv):
+        ctx.set_state(np.concatenate([uv, np.zeros((B, T))], 1), None, np.zeros((B, T, 3)), 0)
+        c = ctx.constr()
+        return 0.5 * (c ** 2).sum(1) + 0.5 * (uv ** 2).sum(1), c
+
+    f0, c0 = objective(u_v)
+    g = ctx.rmult_by_jacob_constr(c0)[:, :ctx.Q - T] + u_v
+    for k in (0, 2, 4, 7, 40):
+        e = np.zeros_like(u_v)
+        e[:, k] = 1e-6
+        fd = (objective(u_v + e)[0] - objective(u_v - e)[0]) / 2e-6
+        assert np.abs(fd - g[:, k]).max() <= 1e-5 * max(1.0, np.abs(g[:, k]).max())
+    q, xo, tries = init.find_initial_states_by_gradient_descent_noisy_system(ctx, rng, adam_step_size=1e-1,
+                                                                             max_iters=5000)
+    assert np.abs(ctx.constr()).max() < 1e-9            # on the manifold
+    assert (np.mean(q[:, -T:] ** 2, 1) < 1.0).all()      # mean squared residual below the threshold
+    assert np.isfinite(ctx.hamiltonian()).all() and (tries >= 1).all()
+    ctx.sample_momentum(1, 1)
+    r = ctx.leapfrog_step(np.full(B, 0.02))
+    assert (r["status"] == 0).mean() >= 0.6
+    ctx.close()
