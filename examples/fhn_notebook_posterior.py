@@ -7,7 +7,10 @@ notebook prints (tests/golden/reference_data/notebook_posterior_table.json), whi
 the reference holds for this path.  The notebook samples with Mici's dynamic multinomial transition; here the batched
 static-trajectory sampler is used (a different Markov kernel for the same posterior), with many more chains.
 
-usage: fhn_notebook_posterior.py [chains] [iterations] [warm-up] [steps per trajectory] [output dir]"""
+With `dynamic` as sixth argument the batched dynamic (no-U-turn, multinomial) transition of dynamic.py is used, the
+counterpart of the notebook's own transition.
+
+usage: fhn_notebook_posterior.py [chains] [iterations] [warm-up] [steps per trajectory] [output dir] [static|dynamic]"""
 import json
 import os
 import sys
@@ -35,7 +38,8 @@ def notebook_data():
     return dict(T=T, S=S, obs_interval=dt_obs, y=x_seq[S - 1::S, 0].copy(), z_ref=z, x_0_ref=x_0, q_ref=q_ref)
 
 
-def run(num_chains=64, n_iter=700, n_warm=200, n_step=24, out_dir=None, seed=20200710, verbose=True):
+def run(num_chains=64, n_iter=700, n_warm=200, n_step=24, out_dir=None, seed=20200710, verbose=True,
+        transition="static"):
     d = notebook_data()
     m = em.fhn_nb
     rng = np.random.default_rng(seed)
@@ -75,7 +79,17 @@ def run(num_chains=64, n_iter=700, n_warm=200, n_step=24, out_dir=None, seed=202
 
     tmp = out_dir or os.path.join(ROOT, "gpurun_out", "fhn_notebook_run")
     t0 = time.time()
-    res = sample_static_chmc(ctx, n_iter, n_step, 0.1, seed=seed, n_adapt=n_warm, trace_dir=tmp, trace_func=trace_func,
+    if transition == "dynamic":
+        from manifold_mcmc_for_diffusions_amd.dynamic import sample_dynamic_chmc
+        res = sample_dynamic_chmc(ctx, n_iter, 0.1, seed=seed, n_adapt=n_warm, trace_dir=tmp, trace_func=trace_func,
+                                  solver=dict(newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10,
+                                              max_iters=50, reverse_check_tol=2e-8),
+                                  callback=(lambda it, h, a, e, st: (it % 50 == 0) and print(
+                                      f"  iter {it:4d} accept {a:.2f} step {e:.3f} n_step {st['n_step'].mean():.1f} "
+                                      f"integrator errors {st['integrator_error'].mean():.2f}", flush=True)) if verbose else None)
+        res["fail_rate"] = res["integrator_error"]
+    else:
+      res = sample_static_chmc(ctx, n_iter, n_step, 0.1, seed=seed, n_adapt=n_warm, trace_dir=tmp, trace_func=trace_func,
                              jitter_length=True,
                              solver=dict(newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10,
                                          max_iters=50, reverse_check_tol=2e-8),  # cell 33
@@ -99,7 +113,8 @@ def run(num_chains=64, n_iter=700, n_warm=200, n_step=24, out_dir=None, seed=202
         print(f"{int(moving.sum())} of {num_chains} chains moving in the main phase (summary over those)")
         print(f"{num_chains} chains x {n_iter} transitions x <= {n_step} steps in {el:.1f} s; final step size "
               f"{res['final_step_size']:.3f}, accept {res['accept_stat'][n_warm:].mean():.2f}, failed trajectories "
-              f"{res['fail_rate'][n_warm:].mean():.3f}")
+              f"{res['fail_rate'][n_warm:].mean():.3f}" + (f", mean tree size {res['n_step'][n_warm:].mean():.1f} steps"
+                                                             if transition == "dynamic" else ""))
         print("  var      mean (notebook)     sd (notebook)     r_hat   ess    z = diff / combined mcse")
         for r in rows:
             print(f"  {r['var']:7s} {r['mean']:7.3f} ({r['ref_mean']:6.3f})   {r['sd']:6.3f} ({r['ref_sd']:5.3f})   "
@@ -111,4 +126,5 @@ def run(num_chains=64, n_iter=700, n_warm=200, n_step=24, out_dir=None, seed=202
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    run(*(int(x) for x in a[:4]), out_dir=a[4] if len(a) > 4 else None)
+    run(*(int(x) for x in a[:4]), out_dir=a[4] if len(a) > 4 and a[4] != "-" else None,
+        transition=a[5] if len(a) > 5 else "static")

@@ -89,6 +89,10 @@ int chmc_sample_momentum(chmc_ctx* ctx, unsigned long long seed, unsigned long l
  * first n components of every chain's position ([B][n]: u and v_0 live there, cf. trace_func of the scripts). */
 int chmc_snapshot(chmc_ctx* ctx);
 int chmc_restore(chmc_ctx* ctx, const int* mask);
+/* The same from caller-held device buffers q_dev, p_dev [B][Q] (e.g. the tree edges of a dynamic transition): chains
+ * with mask != 0 get (pos, mom) from the buffers and their state caches re-evaluated; momentum_is_tangent tells the
+ * library whether those momenta lie in the cotangent space of their positions (see chmc_leapfrog_step). */
+int chmc_restore_device(chmc_ctx* ctx, const void* q_dev, const void* p_dev, const int* mask, int momentum_is_tangent);
 int chmc_get_head(chmc_ctx* ctx, int n, double* out);
 /* system.update_x_obs_seq(state) (:1240-1241, :384-397) */
 int chmc_update_x_obs_seq(chmc_ctx* ctx);

@@ -42,6 +42,7 @@ SYMBOLS = [
     ("chmc_sample_momentum", C.c_int, [C.c_void_p, C.c_ulonglong, C.c_ulonglong, C.c_int]),
     ("chmc_snapshot", C.c_int, [C.c_void_p]),
     ("chmc_restore", C.c_int, [C.c_void_p, ip]),
+    ("chmc_restore_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.c_int]),
     ("chmc_get_head", C.c_int, [C.c_void_p, C.c_int, dp]),
     ("chmc_update_x_obs_seq", C.c_int, [C.c_void_p]),
     ("chmc_switch_partition", C.c_int, [C.c_void_p]),
@@ -98,6 +99,13 @@ def lib():
             raise RuntimeError(
                 f"{_SO} not found: the HIP extension has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        # PyTorch-ROCm ships its own HIP runtime; if this library pulled in the system one first, a later
+        # torch.cuda initialisation in the same process finds no devices.  Whoever uses torch next to the library
+        # (bench.py's gather, the dynamic transition's tree vectors) therefore gets torch's runtime loaded first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _LIB = _bind(C.CDLL(_SO))
     return _LIB
 

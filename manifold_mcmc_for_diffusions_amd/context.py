@@ -113,6 +113,11 @@ class ChmcContext:
         m = np.ascontiguousarray(mask, dtype=np.int32)
         check(self.L.chmc_restore(self.h, iptr(m)), "chmc_restore")
 
+    def restore_device(self, q_dev_ptr, p_dev_ptr, mask, momentum_is_tangent=True):
+        m = np.ascontiguousarray(mask, dtype=np.int32)
+        check(self.L.chmc_restore_device(self.h, C.c_void_p(q_dev_ptr), C.c_void_p(p_dev_ptr), iptr(m),
+                                         int(bool(momentum_is_tangent))), "chmc_restore_device")
+
     def get_head(self, n):
         out = np.empty((self.B, n))
         check(self.L.chmc_get_head(self.h, int(n), ptr(out)), "chmc_get_head")

@@ -1,0 +1,229 @@
+"""Batched dynamic-integration-time transition: the caller of the hot path in the reference's experiments
+(mici.transitions.MultinomialDynamicIntegrationTransition, wired in scripts/utils.py:292-301).
+
+Mici builds the trajectory tree of one chain recursively.  Here every chain of a context grows its own tree in lock
+step: at tree depth d every live chain picks its own direction, resumes from its own tree edge and takes 2^d leapfrog
+steps; multinomial sampling of the proposal (uniform within a sub-tree, biased progressive between the old tree and a
+new sub-tree), the no-U-turn criterion `dh_dmom(edge) . sum_mom < 0` on every sub-tree span (checked iteratively with
+O(depth) momentum checkpoints per chain instead of recursion), termination on integrator errors and on divergence
+(`delta_h > max_delta_h`) follow the reference's transition; Mici's additional "extra sub-tree checks" are not made.
+Tree vectors (edges, proposal, momentum sums, checkpoints) live in torch tensors on the context's device -- plumbing
+around `chmc_leapfrog_step`, which does all the work -- and the library re-evaluates a chain's state caches when its
+tree switches edges (`chmc_restore_device`), one batched evaluation per doubling at most.
+
+All random choices come from `TreeUniforms`, keyed by (seed, transition, purpose, depth, leaf) and the global chain
+index, so results do not depend on how chains are sharded or on the order in which an implementation asks for them.
+"""
+import numpy as np
+
+
+class TreeUniforms:
+    """U(0, 1) draws of one transition: `get(kind, depth, leaf)` -> [B] for this rank's chains."""
+    DIRECTION, ACCEPT, LEAF = 0, 1, 2
+
+    def __init__(self, seed, transition, total_chains, chain_offset, num_chains):
+        self.key = (int(seed), int(transition))
+        self.total, self.off, self.B = total_chains, chain_offset, num_chains
+
+    def get(self, kind, depth, leaf=0):
+        rng = np.random.default_rng(self.key + (int(kind), int(depth), int(leaf)))
+        return rng.random(self.total)[self.off:self.off + self.B]
+
+
+def _ckpt_range(k):
+    """Checkpoint slots touched by leaf k of a sub-tree (Phan & Pradhan's iterative no-U-turn check): idx_max = number
+    of set bits of k >> 1, idx_min = idx_max - (number of trailing set bits of k) + 1."""
+    idx_max = bin(k >> 1).count("1")
+    trailing = 0
+    n = k
+    while n & 1:
+        n >>= 1
+        trailing += 1
+    return idx_max - trailing + 1, idx_max
+
+
+class DynamicTransition:
+    """state = the context's current chain states; `sample(it)` runs one transition for every chain and leaves the
+    selected states set on the context (momentum to be refreshed by the caller)."""
+
+    def __init__(self, ctx, step_size, seed, max_tree_depth=10, max_delta_h=1000.0, solver=None, chain_offset=0,
+                 total_chains=None, device=None):
+        import torch
+        self.torch = torch
+        self.ctx, self.step_size, self.seed = ctx, float(step_size), seed
+        self.max_tree_depth, self.max_delta_h = int(max_tree_depth), float(max_delta_h)
+        self.solver = dict(newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10, max_iters=50,
+                           reverse_check_tol=2e-8) if solver is None else solver
+        self.off = chain_offset
+        self.total = ctx.B + chain_offset if total_chains is None else total_chains
+        if device is None:
+            device = torch.device("cuda", 0) if ctx.L.chmc_backend().startswith(b"hip") else torch.device("cpu")
+        self.dev = device
+        B, Q = ctx.B, ctx.Q
+        z = lambda *s: torch.zeros(s, dtype=torch.float64, device=device)  # noqa: E731
+        self.q, self.p = z(B, Q), z(B, Q)                       # staging of the context's current state
+        self.neg_q, self.neg_p, self.pos_q, self.pos_p = z(B, Q), z(B, Q), z(B, Q), z(B, Q)
+        self.prop_q, self.sub_prop_q = z(B, Q), z(B, Q)
+        self.sum_mom, self.sub_sum = z(B, Q), z(B, Q)
+        self.ck_p = z(self.max_tree_depth, B, Q)                # momentum at the first leaf of a pending span
+        self.ck_sum = z(self.max_tree_depth, B, Q)              # running sub-tree momentum sum at that leaf
+
+    # ---- helpers
+    def _sync(self):
+        if self.dev.type == "cuda":
+            self.torch.cuda.synchronize(self.dev)
+
+    def _fetch(self):
+        self._sync()
+        self.ctx.get_state_device(self.q.data_ptr(), self.p.data_ptr())
+
+    def _mask(self, m):
+        return self.torch.from_numpy(np.ascontiguousarray(m)).to(self.dev)
+
+    def sample(self, it):
+        torch, ctx = self.torch, self.ctx
+        B = ctx.B
+        un = TreeUniforms(self.seed, it, self.total, self.off, B)
+        self._fetch()
+        h0 = ctx.hamiltonian()[:, 0]
+        for t in (self.neg_q, self.pos_q, self.prop_q):
+            t.copy_(self.q)
+        for t in (self.neg_p, self.pos_p, self.sum_mom):
+            t.copy_(self.p)
+        logw = -h0.copy()
+        at_pos = np.ones(B, dtype=bool)          # which edge the context currently holds (both at depth 0)
+        at_neg = np.ones(B, dtype=bool)
+        alive = np.isfinite(h0)
+        moved = np.zeros(B, dtype=bool)
+        sum_acc, n_step = np.zeros(B), np.zeros(B, dtype=np.int64)
+        depth_reached = np.zeros(B, dtype=np.int64)
+        diverged, failed = np.zeros(B, dtype=bool), np.zeros(B, dtype=bool)
+        for d in range(self.max_tree_depth):
+            if not alive.any():
+                break
+            fwd = un.get(un.DIRECTION, d) < 0.5
+            # bring the context to the edge each live chain extends from
+            need = alive & np.where(fwd, ~at_pos, ~at_neg)
+            if need.any():
+                src_q = torch.where(self._mask(fwd)[:, None], self.pos_q, self.neg_q)
+                src_p = torch.where(self._mask(fwd)[:, None], self.pos_p, self.neg_p)
+                self._sync()
+                ctx.restore_device(src_q.data_ptr(), src_p.data_ptr(), need.astype(np.int32), True)
+            at_pos = np.where(alive, fwd, at_pos)
+            at_neg = np.where(alive, ~fwd, at_neg)
+            dt = np.where(fwd, self.step_size, -self.step_size)
+            # ---- sub-tree of 2^d leaves
+            run = alive.copy()
+            sub_logw = np.full(B, -np.inf)
+            self.sub_sum.zero_()
+            for k in range(1 << d):
+                if not run.any():
+                    break
+                r = ctx.leapfrog_step(dt, active=run.astype(np.int32), **self.solver)
+                bad = run & (r["status"] != 0)
+                failed |= bad
+                self._fetch()
+                h = ctx.hamiltonian()[:, 0]
+                div = run & ~bad & ~((h - h0) <= self.max_delta_h)   # NaN counts as divergent
+                diverged |= div
+                stop = bad | div
+                alive &= ~stop
+                run &= ~stop
+                n_step += run
+                sum_acc += np.where(run, np.minimum(1.0, np.exp(np.minimum(0.0, h0 - h))), 0.0)
+                leaf_logw = np.where(run, -h, -np.inf)
+                new_logw = np.logaddexp(sub_logw, leaf_logw)
+                take = run & (un.get(un.LEAF, d, k) < np.exp(np.where(run, leaf_logw - np.where(run, new_logw, 0.0), -np.inf)))
+                sub_logw = np.where(run, new_logw, sub_logw)
+                tm, rm = self._mask(take), self._mask(run)
+                self.sub_prop_q.copy_(torch.where(tm[:, None], self.q, self.sub_prop_q))
+                self.sub_sum.add_(torch.where(rm[:, None], self.p, torch.zeros_like(self.p)))
+                # iterative no-U-turn checks over every sub-tree span that ends at this leaf
+                lo, hi = _ckpt_range(k)
+                if k % 2 == 0:
+                    self.ck_p[hi].copy_(self.p)
+                    self.ck_sum[hi].copy_(self.sub_sum)
+                else:
+                    turning = torch.zeros(B, dtype=torch.bool, device=self.dev)
+                    for i in range(hi, lo - 1, -1):
+                        span = self.sub_sum - self.ck_sum[i] + self.ck_p[i]
+                        turning |= ((self.ck_p[i] * span).sum(1) < 0) | ((self.p * span).sum(1) < 0)
+                    turn = run & turning.cpu().numpy()
+                    alive &= ~turn
+                    run &= ~turn
+            done = run  # chains whose sub-tree completed without terminating
+            if not done.any():
+                continue
+            depth_reached = np.where(done, d + 1, depth_reached)
+            # biased progressive sampling between the old tree and the new sub-tree
+            acc = done & (un.get(un.ACCEPT, d) < np.exp(np.minimum(0.0, sub_logw - logw)))
+            moved |= acc
+            am, dm = self._mask(acc), self._mask(done)
+            self.prop_q.copy_(torch.where(am[:, None], self.sub_prop_q, self.prop_q))
+            logw = np.where(done, np.logaddexp(logw, sub_logw), logw)
+            self.sum_mom.add_(torch.where(dm[:, None], self.sub_sum, torch.zeros_like(self.sub_sum)))
+            fm = self._mask(done & fwd)[:, None]
+            bm = self._mask(done & ~fwd)[:, None]
+            self.pos_q.copy_(torch.where(fm, self.q, self.pos_q))
+            self.pos_p.copy_(torch.where(fm, self.p, self.pos_p))
+            self.neg_q.copy_(torch.where(bm, self.q, self.neg_q))
+            self.neg_p.copy_(torch.where(bm, self.p, self.neg_p))
+            # no-U-turn criterion on the whole tree (riemannian_no_u_turn_criterion with the identity metric)
+            turn = (((self.neg_p * self.sum_mom).sum(1) < 0) | ((self.pos_p * self.sum_mom).sum(1) < 0)).cpu().numpy()
+            alive &= ~(done & turn)
+        # leave the selected positions on the context (every chain: the context may sit on a tree edge)
+        self._sync()
+        ctx.restore_device(self.prop_q.data_ptr(), self.p.data_ptr(), np.ones(B, dtype=np.int32), False)
+        return dict(accept_stat=sum_acc / np.maximum(n_step, 1), n_step=n_step, depth=depth_reached, moved=moved,
+                    diverged=diverged, integrator_error=failed)
+
+
+def sample_dynamic_chmc(ctx, n_iter, step_size, seed, n_adapt=0, chain_offset=0, total_chains=None, n_head=6,
+                        trace_dir=None, trace_func=None, callback=None, **kw):
+    """Momentum refresh -> dynamic transition -> partition switch, `n_iter` times for all chains of `ctx`, with
+    dual-averaging step-size adaptation on the tree's accept statistic (combined over all ranks) during warm-up:
+    the reference's sampling loop (scripts/utils.py:292-306, 338-365), batched."""
+    import time
+    from .sampling import DualAveragingStepSize, _mean_over_all_chains
+    tr = DynamicTransition(ctx, step_size, seed, chain_offset=chain_offset, total_chains=total_chains, **kw)
+    adapter = DualAveragingStepSize(step_size) if n_adapt > 0 else None
+    B = ctx.B
+    heads = np.empty((n_iter, B, n_head))
+    acc_hist, eps_hist, nstep_hist = np.empty(n_iter), np.empty(n_iter), np.empty(n_iter)
+    err_hist = np.empty(n_iter)
+    writer, t0, c0 = None, time.perf_counter(), ctx.counters()
+    if trace_func is None:
+        def trace_func(head, ham):
+            return {"pos_head": head, "hamiltonian": ham}
+    for it in range(n_iter):
+        ctx.sample_momentum(seed, it + 1, chain_offset)
+        st = tr.sample(it)
+        ctx.switch_partition()
+        heads[it] = ctx.get_head(n_head)
+        if trace_dir is not None:
+            from .traces import TraceWriter
+            vals = {k: np.asarray(v) for k, v in trace_func(heads[it], ctx.hamiltonian()[:, 0]).items()}
+            if writer is None:
+                writer = TraceWriter(trace_dir, B, n_iter, {k: v.shape[1:] for k, v in vals.items()})
+            writer.write(it, vals)
+        acc = _mean_over_all_chains(st["accept_stat"].sum(), B)
+        acc_hist[it], eps_hist[it] = acc, tr.step_size
+        nstep_hist[it], err_hist[it] = st["n_step"].mean(), st["integrator_error"].mean()
+        if adapter is not None and it < n_adapt:
+            tr.step_size = adapter.update(acc)
+            if it == n_adapt - 1:
+                tr.step_size = adapter.final()
+        if callback is not None:
+            callback(it, heads[it], acc, tr.step_size, st)
+    out = dict(heads=heads, accept_stat=acc_hist, step_size=eps_hist, n_step=nstep_hist, integrator_error=err_hist,
+               final_step_size=tr.step_size)
+    if writer is not None:
+        from .traces import save_summary
+        writer.flush()
+        c1 = ctx.counters()
+        main = {k: np.asarray(v)[:, n_adapt:] for k, v in writer.arrays().items()}
+        out["summary"] = save_summary(trace_dir, main, None, time.perf_counter() - t0, tr.step_size,
+                                      {k: c1[k] - c0[k] for k in c1 if k != "_"})
+        import os
+        out["trace_files"] = {k: os.path.join(trace_dir, f"trace_{k}.npy") for k in writer.arrays()}
+    return out

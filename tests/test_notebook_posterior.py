@@ -34,3 +34,22 @@ def test_posterior_matches_the_notebook_table(tmp_path):
         assert abs(r["z"]) < 4.0, r                     # means agree within Monte-Carlo error
         assert 0.75 < r["sd"] / r["ref_sd"] < 1.25, r   # posterior spread agrees
         assert r["r_hat"] < 1.1, r
+
+
+@pytest.mark.timeout(900)
+def test_posterior_and_sampler_statistics_with_the_dynamic_transition(tmp_path):
+    """The same experiment with the batched dynamic (no-U-turn, multinomial) transition, the counterpart of the
+    notebook's own MultinomialDynamicIntegrationTransition: besides the posterior table, the statistics the notebook's
+    progress bar reports after adaptation (accept_stat 0.83, n_step 28.3, convergence_error 0.15) are of the same
+    size."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import fhn_notebook_posterior as nb
+    rows, res, n_moving = nb.run(64, 450, 150, 0, out_dir=str(tmp_path / "run"), verbose=False, transition="dynamic")
+    assert n_moving >= 45
+    assert 0.7 < res["accept_stat"][150:].mean() < 0.92
+    assert 15.0 < res["n_step"][150:].mean() < 45.0
+    assert res["integrator_error"][150:].mean() < 0.4
+    for r in rows:
+        assert abs(r["z"]) < 4.0, r
+        assert 0.75 < r["sd"] / r["ref_sd"] < 1.25, r
+        assert r["r_hat"] < 1.1, r
