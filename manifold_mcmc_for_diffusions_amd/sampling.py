@@ -1,10 +1,11 @@
-"""A minimal batched sampler on top of the device step: static-length constrained HMC trajectories with a Metropolis
-accept step, momentum refresh, partition switching and dual-averaging step-size adaptation.
+"""A minimal batched sampler on top of the device step: static-length (optionally jittered) constrained HMC
+trajectories with a Metropolis accept step, momentum refresh, partition switching and dual-averaging step-size
+adaptation.
 
 The reference drives the same integrator with Mici's dynamic multinomial (NUTS-style) transition
-(scripts/utils.py:292-306); that transition is a caller of the hot path and out of this round's scope (SURVEY.md
-8f #2).  This static variant targets the same posterior (it is a valid Markov kernel for it) and exists to exercise
-the path end to end: momentum -> L constrained leapfrog steps -> accept / reject -> SwitchPartitionTransition."""
+(scripts/utils.py:292-306); the batched counterpart of that transition is dynamic.py.  This static variant targets the
+same posterior (it is a valid Markov kernel for it), costs no per-leaf bookkeeping and is what bench-like workloads
+use: momentum -> L constrained leapfrog steps -> accept / reject -> SwitchPartitionTransition."""
 import os
 import numpy as np
 
