@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end example on an MI355X: posterior sampling for the FitzHugh-Nagumo model with noisy observations
 (the configuration of scripts/fhn_model_noisy_obs_chmc_experiment.py in the reference: T = 100 observations,
-R = 5, sigma_y = 0.1) with batched constrained HMC.   usage: fhn_noisy_chmc.py [chains] [S] [iters] [warm-up] [output dir]
+R = 5, sigma_y = 0.1) with batched constrained HMC.   usage: fhn_noisy_chmc.py [chains] [S] [iters] [warm-up] [output dir] [static|dynamic]
 With an output directory the traced variables of the reference's trace function (sigma, epsilon, gamma, beta, x_0,
 hamiltonian) are written as memory-mapped `.npy` files together with `summary.json`."""
 import os
@@ -18,7 +18,8 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 n_iter = int(sys.argv[3]) if len(sys.argv) > 3 else 150
 n_warm = int(sys.argv[4]) if len(sys.argv) > 4 else 50
-out_dir = sys.argv[5] if len(sys.argv) > 5 else None
+out_dir = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "-" else None
+dynamic = len(sys.argv) > 6 and sys.argv[6] == "dynamic"  # the reference's transition (no-U-turn trees) instead of 16 fixed steps
 
 
 def trace_func(head, ham):  # scripts/fhn_model_noisy_obs_chmc_experiment.py:82-99
@@ -31,14 +32,24 @@ t0 = time.time()
 wl = FhnWorkload(B, num_steps_per_obs=S, device_init=True)  # initial states solved on the device
 print(f"set-up {time.time() - t0:.1f} s: {B} chains, dim_q = {wl.ctx.Q}", flush=True)
 t0 = time.time()
-res = sample_static_chmc(wl.ctx, n_iter, 16, 0.1, seed=wl.seed, n_adapt=n_warm, trace_dir=out_dir, trace_func=trace_func,
-                         callback=lambda it, h, a, e: (it % 10 == 0) and print(
-                             f"  iter {it:4d} accept {a:.2f} step {e:.3f} z-median {np.median(em.fhn.generate_z(h[:, :4]), 0).round(3)}",
-                             flush=True))
+if dynamic:
+    from manifold_mcmc_for_diffusions_amd.dynamic import sample_dynamic_chmc  # noqa: E402
+    res = sample_dynamic_chmc(wl.ctx, n_iter, 0.1, seed=wl.seed, n_adapt=n_warm, trace_dir=out_dir, trace_func=trace_func,
+                              callback=lambda it, h, a, e, st: (it % 10 == 0) and print(
+                                  f"  iter {it:4d} accept {a:.2f} step {e:.3f} steps per tree {st['n_step'].mean():.1f} "
+                                  f"z-median {np.median(em.fhn.generate_z(h[:, :4]), 0).round(3)}", flush=True))
+    res["fail_rate"] = res["integrator_error"]
+    steps_total = float(res["n_step"].sum()) * B
+else:
+    res = sample_static_chmc(wl.ctx, n_iter, 16, 0.1, seed=wl.seed, n_adapt=n_warm, trace_dir=out_dir, trace_func=trace_func,
+                             callback=lambda it, h, a, e: (it % 10 == 0) and print(
+                                 f"  iter {it:4d} accept {a:.2f} step {e:.3f} z-median {np.median(em.fhn.generate_z(h[:, :4]), 0).round(3)}",
+                                 flush=True))
+    steps_total = n_iter * 16 * B
 el = time.time() - t0
 z = em.fhn.generate_z(res["heads"][n_warm:, :, :4])  # [iters, B, 4] = sigma, eps, gamma, beta
 x0 = em.fhn.generate_x_0(z, res["heads"][n_warm:, :, 4:6])
-print(f"{n_iter} transitions x 16 steps x {B} chains in {el:.1f} s = {n_iter * 16 * B / el:.0f} leapfrog steps/s "
+print(f"{n_iter} transitions x {'dynamic trees' if dynamic else '16 steps'} x {B} chains in {el:.1f} s = {steps_total / el:.0f} leapfrog steps/s "
       f"(includes momentum refresh, accept/reject, partition switch, host traces)")
 print("final step size", round(res["final_step_size"], 4), "mean accept (main)", res["accept_stat"][n_warm:].mean().round(3),
       "failed trajectories", res["fail_rate"][n_warm:].mean().round(4))
