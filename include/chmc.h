@@ -115,6 +115,12 @@ int chmc_normal_space_component(chmc_ctx* ctx, const double* vct, double* out); 
 int chmc_project_onto_cotangent_space(chmc_ctx* ctx);  /* :1252-1254, in place on the state's momentum */
 int chmc_hamiltonian(chmc_ctx* ctx, double* h);        /* :1186-1202  [B][3] = {h1 + h2, q.q/2, p.p/2} */
 
+/* conditioned_diffusion_neg_log_dens_and_grad (sde/mici_extensions.py:82-205), the target of the reference's
+ * unconstrained-HMC comparator, for B independent points: q [B][QH], QH = U + V0 + T S V (no observation-noise part),
+ *   value [B] = 1/2 sum_t ((y_t - obs_func(x_t)) / sigma)^2 + T log sigma (+ 1/2 q.q unless use_gaussian_splitting),
+ *   grad [B][QH] (may be NULL).  Needs a context with observation noise; does not touch the chain states. */
+int chmc_neg_log_dens_and_grad(chmc_ctx* ctx, const double* q, int use_gaussian_splitting, double* value, double* grad);
+
 /* Projection solvers (newton != 0: newton_projection :1065-1135 with its host wrapper :1405-1476;
  * newton == 0: quasi_newton_projection :999-1063 / :1323-1402).  Projects the points q [B][Q] onto the manifold
  * along the rows of the constraint Jacobian at the CURRENT state (= `state_prev` of the reference).

@@ -204,6 +204,18 @@ class ChmcContext:
         check(self.L.chmc_hamiltonian(self.h, ptr(h)), "chmc_hamiltonian")
         return h
 
+    def neg_log_dens_and_grad(self, q, use_gaussian_splitting=False, want_grad=True):
+        """conditioned_diffusion_neg_log_dens_and_grad (sde/mici_extensions.py:82-205) at q [B, U + V0 + T S V]."""
+        QH = self.U + self.NV
+        q = as_c(q)
+        if q.shape != (self.B, QH):
+            raise ValueError(f"q must have shape ({self.B}, {QH}), got {q.shape}")
+        val = np.empty(self.B)
+        g = np.empty((self.B, QH)) if want_grad else None
+        check(self.L.chmc_neg_log_dens_and_grad(self.h, ptr(q), int(bool(use_gaussian_splitting)), ptr(val), ptr(g)),
+              "chmc_neg_log_dens_and_grad")
+        return val, g
+
     def project(self, q, dt, newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10, max_iters=50):
         q = self._bq(q, "q")
         dt = as_c(np.broadcast_to(np.asarray(dt, dtype=np.float64), (self.B,)))

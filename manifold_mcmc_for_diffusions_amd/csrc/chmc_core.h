@@ -642,6 +642,34 @@ struct KXobs {
   }
 };
 
+// Forward half of conditioned_diffusion_neg_log_dens_and_grad (:82-205, the unconstrained-HMC comparator of the
+// reference's experiments) when the steps per observation do not tile by 8 (otherwise k_fwd_scan runs the whole
+// chain as one block): the full T * S-step scan of one chain from q = [u | v_0 | v_seq], storing the trajectory.
+template <class M>
+struct KFullScan {
+  Sys sy;
+  const double* qin;  // [B][QH], QH = U + V0 + T S V
+  double* traj;       // [B][TRJ]
+  int QH;
+  CHMC_HD void operator()(int c) const {
+    constexpr int X = M::X, V = M::V;
+    const double* q = qin + (size_t)c * QH;
+    ChainConsts<M> cc;
+    cc.init(q, sy.dl);
+    double x[X], xn[X];
+    M::gx0(cc.z, q + sy.U, x);
+    const double* v = q + sy.U + sy.V0;
+    double* tr = traj + (size_t)c * sy.TRJ;
+    const int L = sy.T * sy.S;
+    for (int s = 0; s < L; ++s) {
+      for (int a = 0; a < X; ++a) tr[(size_t)s * X + a] = x[a];
+      M::step(cc.k, x, v + (size_t)s * V, xn);
+      for (int a = 0; a < X; ++a) x[a] = xn[a];
+    }
+    for (int a = 0; a < X; ++a) tr[(size_t)L * X + a] = x[a];
+  }
+};
+
 // State evaluation, block part: trajectory, Jacobian rows, Gram block, its Cholesky factor,
 // D^-1 dc/du and this block's contribution to C (jacob_constr_blocks + chol_gram_blocks :626-687)
 template <class M, int RM>

@@ -431,6 +431,153 @@ __global__ void __launch_bounds__(256) k_gram_rows(Sys sy, Slots sl, Work w, int
   }
 }
 
+// Backward half of conditioned_diffusion_neg_log_dens_and_grad (:82-205): value and gradient of
+//   1/2 sum_t ((y_t - obs_func(x_t)) / sigma)^2 + T log sigma [+ 1/2 q^T q]        (fixed sigma, Y = 1)
+// by ONE adjoint sweep over the whole trajectory of a chain: one wavefront per chain, 64 consecutive steps per tile as
+// in k_rev_wave, a single adjoint row that picks up -r_t / sigma^2 * d obs_func at every observation time.
+template <class M>
+__global__ void __launch_bounds__(256) k_nld_grad_wave(Sys sy, const double* qin, const double* trajb, int QH,
+                                                       int gaussian, double* val, double* grad) {
+  constexpr int X = M::X, V = M::V, Z = M::Z, V0 = M::V0;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (c >= sy.B) return;
+  const double* q = qin + (size_t)c * QH;
+  const double* traj = trajb + (size_t)c * sy.TRJ;
+  double* g = grad ? grad + (size_t)c * QH : nullptr;
+  const double* vbase = q + sy.U + sy.V0;
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  const int S = sy.S, ntile = (S + 63) >> 6;
+  const double is2 = 1.0 / (sy.sigma * sy.sigma);
+  double Lam[X], zacc[Z], vsq = 0.0, rsq = 0.0;
+#pragma unroll
+  for (int a = 0; a < X; ++a) Lam[a] = 0.0;
+#pragma unroll
+  for (int a = 0; a < Z; ++a) zacc[a] = 0.0;
+  for (int j = sy.T - 1; j >= 0; --j) {
+    {  // source of observation j: d/dx_t [1/2 r_t^2 / sigma^2] = -r_t / sigma^2 * d obs_func(x_t)
+      double og[X];
+      const double* xo = traj + (size_t)(j + 1) * S * X;  // state at observation time j (wave-uniform)
+      M::obs_grad(xo, og);
+      const double rj = sy.y[j] - M::obs(xo);
+      rsq += rj * rj;
+      const double wj = -rj * is2;
+#pragma unroll
+      for (int a = 0; a < X; ++a) Lam[a] += wj * og[a];
+    }
+    for (int t = ntile - 1; t >= 0; --t) {
+      const int off = (t << 6) + lane;
+      const bool valid = off < S;
+      const int s = j * S + off;
+      double A[X * X], Bm[X * V], Zf[X * Z], vv[V];
+      if (valid) {
+        double x[X];
+#pragma unroll
+        for (int a = 0; a < X; ++a) x[a] = traj[(size_t)s * X + a];
+#pragma unroll
+        for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
+        M::jac(cc.k, x, vv, A, Bm, Zf);
+      } else {
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+#pragma unroll
+        for (int a = 0; a < V; ++a) vv[a] = 0.0;
+      }
+      double Inc[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {  // inclusive suffix products (later steps on the left)
+        double Y[X * X], P[X * X];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o, 64);
+        matmul_xx<X>(Y, Inc, P);
+        if (lane + o < 64) {
+#pragma unroll
+          for (int i = 0; i < X * X; ++i) Inc[i] = P[i];
+        }
+      }
+      double E[X * X], I0[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) {
+        const double yv = __shfl_down(Inc[i], 1, 64);
+        E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : yv;
+        I0[i] = bcast0(Inc[i]);
+      }
+      double Ls[X];
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        double tt = 0.0;
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += Lam[a] * E[a * X + d];
+        Ls[d] = tt;
+      }
+      if (valid) {
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          double tt = gaussian ? 0.0 : vv[d];
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt += Ls[a] * Bm[a * V + d];
+          if (g) g[sy.U + sy.V0 + (size_t)s * V + d] = tt;
+          vsq += vv[d] * vv[d];
+        }
+      }
+#pragma unroll
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt = zacc[mz];
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += Ls[a] * Zf[a * Z + mz];
+        zacc[mz] = tt;
+      }
+      double nl[X];
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        double tt = 0.0;
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += Lam[a] * I0[a * X + d];
+        nl[d] = tt;
+      }
+#pragma unroll
+      for (int d = 0; d < X; ++d) Lam[d] = nl[d];
+    }
+  }
+#pragma unroll
+  for (int mz = 0; mz < Z; ++mz) {
+    double v = zacc[mz];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    zacc[mz] = v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) vsq += __shfl_xor(vsq, o, 64);
+  if (lane == 0) {
+    double dz[X * Z], dv0[X * V0], G[Z * Z];
+    M::gx0_jac(dz, dv0);
+    M::gz_jac(q, G);
+    for (int mz = 0; mz < Z; ++mz)
+      for (int a = 0; a < X; ++a) zacc[mz] += Lam[a] * dz[a * Z + mz];
+    double qsq = vsq;
+    for (int d = 0; d < V0; ++d) {
+      double tt = gaussian ? 0.0 : q[sy.U + d];
+      for (int a = 0; a < X; ++a) tt += Lam[a] * dv0[a * V0 + d];
+      if (g) g[sy.U + d] = tt;
+      qsq += q[sy.U + d] * q[sy.U + d];
+    }
+    for (int d = 0; d < Z; ++d) {
+      double tt = gaussian ? 0.0 : q[d];
+      for (int mz = 0; mz < Z; ++mz) tt += zacc[mz] * G[mz * Z + d];
+      if (g) g[d] = tt;
+      qsq += q[d] * q[d];
+    }
+    val[c] = 0.5 * rsq * is2 + sy.T * log(sy.sigma) + (gaussian ? 0.0 : 0.5 * qsq);
+  }
+}
+
 // J w (lmult_by_jacob_constr :822-877): one wave per (chain, block); lanes stride over the block's columns
 // (unit-stride loads of the RM stored rows and of the vector), butterfly reduction, lane 0 adds the dc/du and
 // dc/dn terms.  Result in work.cpad.

@@ -13,7 +13,7 @@ import itertools
 from numbers import Number
 import numpy as np
 from .context import ChmcContext
-from .errors import ConvergenceError
+from .errors import ConvergenceError, HamiltonianDivergenceError
 from .example_models import ModelHandle
 
 _tokens = itertools.count(1)
@@ -319,3 +319,53 @@ def find_initial_state_by_linear_interpolation(system, rng, generate_x_obs_seq_i
     state = ConditionedDiffusionHamiltonianState(pos=q, x_obs_seq=x_obs_seq)
     state.mom = system.sample_momentum(state, rng)
     return state
+
+
+def conditioned_diffusion_neg_log_dens_and_grad(obs_interval, num_steps_per_obs, y_seq, dim_u, dim_v_0, dim_v,
+                                                forward_func, generate_x_0, generate_z, generate_σ, obs_func,
+                                                use_gaussian_splitting=False, return_jax_funcs=False, *, device=0):
+    """sde/mici_extensions.py:82-205: negative log target density and its gradient for the unconstrained-HMC comparator
+    of the reference's experiments (to be used with a Mici `EuclideanMetricSystem`).  The model functions are the
+    handles of one compiled model; `generate_σ` must be a number (fixed observation noise).  Returns
+    `(neg_log_dens, grad_neg_log_dens)` with the reference's conventions: `grad_neg_log_dens(q) -> (grad, value)`, a
+    non-finite value raises `HamiltonianDivergenceError`.  A leading batch axis on `q` evaluates that many points in
+    one launch (the context is re-created when the batch size changes)."""
+    from numbers import Number
+    handles = (forward_func, generate_x_0, generate_z, obs_func)
+    if not all(isinstance(h, ModelHandle) for h in handles) or len({h.model for h in handles}) != 1:
+        raise TypeError("forward_func, generate_x_0, generate_z and obs_func must be the handles of one compiled model")
+    if not isinstance(generate_σ, Number):
+        raise NotImplementedError("variable observation noise (callable generate_σ) is not supported")
+    if return_jax_funcs:
+        raise NotImplementedError("there are no JAX functions behind this implementation")
+    model = forward_func.model
+    if (dim_u, dim_v_0, dim_v) != (model.dim_z, model.dim_v_0, model.dim_v):
+        raise ValueError("dim_u, dim_v_0, dim_v do not match the compiled model")
+    y = np.asarray(y_seq, dtype=np.float64).reshape(-1)
+    ctxs = {}
+
+    def _eval(q, want_grad):
+        q = np.asarray(q, dtype=np.float64)
+        q2 = np.atleast_2d(q)
+        B = q2.shape[0]
+        if B not in ctxs:
+            for c in ctxs.values():
+                c.close()
+            ctxs.clear()
+            ctxs[B] = ChmcContext(model.name, obs_interval, num_steps_per_obs, None, y, sigma=float(generate_σ),
+                                  num_chains=B, device=device)
+        val, g = ctxs[B].neg_log_dens_and_grad(q2, use_gaussian_splitting, want_grad)
+        if not np.all(np.isfinite(val)):
+            raise HamiltonianDivergenceError("Hamiltonian non-finite")
+        if q.ndim == 1:
+            return (float(val[0]), None if g is None else g[0])
+        return val, g
+
+    def neg_log_dens(q):
+        return _eval(q, False)[0]
+
+    def grad_neg_log_dens(q):
+        val, g = _eval(q, True)
+        return g, val
+
+    return neg_log_dens, grad_neg_log_dens

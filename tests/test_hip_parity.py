@@ -344,3 +344,21 @@ def test_sir_initial_states_by_gradient_descent():
     r = ctx.leapfrog_step(np.full(B, 0.02))
     assert (r["status"] == 0).mean() >= 0.6
     ctx.close()
+
+
+@pytest.mark.parametrize("model,T,S,gaussian", [("fhn", 5, 7, False), ("fhn", 3, 70, True), ("sir", 4, 9, False),
+                                                ("fhn", 4, 16, False), ("sir", 3, 8, True)])  # S % 8 == 0: scan kernel
+def test_unconstrained_hmc_target_matches_autodiff_oracle(model, T, S, gaussian):
+    """chmc_neg_log_dens_and_grad (conditioned_diffusion_neg_log_dens_and_grad, sde/mici_extensions.py:82-205: the
+    reference's unconstrained-HMC comparator) against the torch autograd restatement: value and gradient."""
+    from oracle.py.neg_log_dens import neg_log_dens_and_grad
+    case = make_case(model, T, S, None, True, B=3, seed=61)
+    ctx = make_ctx(case)
+    QH = ctx.U + ctx.NV
+    q = case["q"][:, :QH]
+    val, g = ctx.neg_log_dens_and_grad(q, use_gaussian_splitting=gaussian)
+    for c in range(3):
+        vo, go = neg_log_dens_and_grad(model, case["obs_interval"], S, case["y"], case["sigma"], q[c], gaussian)
+        assert abs(val[c] - vo) <= 1e-10 * max(1.0, abs(vo))
+        assert np.abs(g[c] - go).max() <= 1e-9 * max(1.0, np.abs(go).max())
+    ctx.close()
