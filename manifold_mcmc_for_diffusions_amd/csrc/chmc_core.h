@@ -1316,6 +1316,28 @@ CHMC_HD inline double2_ ld2_stream(const double* p) {
 #endif
   return r;
 }
+// Two adjacent components of a [B][Q] vector for the "row" launches (grid: column pairs x chains).  `wide`: the pair is
+// 16-byte aligned (even Q) and complete; otherwise the components are accessed one by one (`two`: the second exists).
+// Streaming hints as for the Jacobian rows: every vector of the integrator is far larger than the caches' share.
+CHMC_HD inline double2_ ldv2(const double* p, bool wide, bool two) {
+  double2_ r;
+  if (wide) return ld2_stream(p);
+  r.x = p[0], r.y = two ? p[1] : 0.0;
+  return r;
+}
+CHMC_HD inline void stv2(double* p, double2_ v, bool wide, bool two) {
+  if (wide) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_nontemporal_store(v.x, p);
+    __builtin_nontemporal_store(v.y, p + 1);
+#else
+    p[0] = v.x, p[1] = v.y;
+#endif
+    return;
+  }
+  p[0] = v.x;
+  if (two) p[1] = v.y;
+}
 template <int RM, int TGT, int VEC>
 struct KUpdate {
   Sys sy;
@@ -1618,12 +1640,16 @@ struct KKickPg {
   Work w;
   int which, out_other;
   double hfrac;
-  CHMC_HD void operator()(int tid) const {
-    const int c = tid / sy.Q;
-    if (!w.ok[c]) return;
+  CHMC_HD bool active(int c) const { return w.ok[c] != 0; }
+  CHMC_HD void operator()(int c, int col) const {  // row launch: components col, col + 1 of chain c
     const int s = sl.cur[c] ^ which;
     const double h = hfrac * w.dt[c];
-    (out_other ? pick(sl.p, s ^ 1) : pick(sl.p, s))[tid] = pick(sl.p, s)[tid] - h * pick(sl.pg, s)[tid];
+    const size_t i = (size_t)c * sy.Q + col;
+    const bool two = col + 1 < sy.Q, wide = two && !(sy.Q & 1);
+    const double2_ p0 = ldv2(pick(sl.p, s) + i, wide, two), g = ldv2(pick(sl.pg, s) + i, wide, two);
+    double2_ o;
+    o.x = p0.x - h * g.x, o.y = p0.y - h * g.y;
+    stv2((out_other ? pick(sl.p, s ^ 1) : pick(sl.p, s)) + i, o, wide, two);
   }
 };
 // h2_flow (:1222-1231) from slot `from` into (q_out, p_out): dst 0 = other slot, dst 1 = work (qb, pb)
@@ -1633,28 +1659,29 @@ struct KFlow {
   Work w;
   int from, dst, from_p_other;
   double sign;
-  CHMC_HD void operator()(int tid) const {
-    const int c = tid / sy.Q;
-    if (!w.ok[c]) return;
+  CHMC_HD bool active(int c) const { return w.ok[c] != 0; }
+  CHMC_HD void operator()(int c, int col) const {  // row launch: components col, col + 1 of chain c
     const int s = sl.cur[c] ^ from;
     const double dt = sign * w.dt[c];
-    const double q0 = pick(sl.q, s)[tid];
-    const double p0 = from_p_other ? pick(sl.p, s ^ 1)[tid] : pick(sl.p, s)[tid];
-    double qn, pn;
+    const size_t i = (size_t)c * sy.Q + col;
+    const bool two = col + 1 < sy.Q, wide = two && !(sy.Q & 1);
+    const double2_ q0 = ldv2(pick(sl.q, s) + i, wide, two);
+    const double2_ p0 = ldv2((from_p_other ? pick(sl.p, s ^ 1) : pick(sl.p, s)) + i, wide, two);
+    double2_ qn, pn;
     if (sy.gaussian) {  // sin / cos of dt[c] are evaluated once per chain (KBegin), not per component
       const double sn = sign * w.sdt[c], cs = w.cdt[c];
-      qn = q0 * cs + sn * p0;
-      pn = p0 * cs - sn * q0;
+      qn.x = q0.x * cs + sn * p0.x, qn.y = q0.y * cs + sn * p0.y;
+      pn.x = p0.x * cs - sn * q0.x, pn.y = p0.y * cs - sn * q0.y;
     } else {
-      qn = q0 + dt * p0;
+      qn.x = q0.x + dt * p0.x, qn.y = q0.y + dt * p0.y;
       pn = p0;
     }
     if (dst == 0) {
-      pick(sl.q, s ^ 1)[tid] = qn;
+      stv2(pick(sl.q, s ^ 1) + i, qn, wide, two);
       // (standard splitting: the flow leaves the momentum as it is, and it already sits in the destination slot)
-      if (sy.gaussian || !from_p_other) pick(sl.p, s ^ 1)[tid] = pn;
+      if (sy.gaussian || !from_p_other) stv2(pick(sl.p, s ^ 1) + i, pn, wide, two);
     } else {
-      w.qb[tid] = qn;  // reverse-check flow: only the position is compared (KRevDiff), the momentum is not kept
+      stv2(w.qb + i, qn, wide, two);  // reverse-check flow: only the position is compared (KRevDiff), the momentum is not kept
     }
   }
 };
@@ -1689,21 +1716,26 @@ struct KMomFixInitPg {
   Slots sl;
   Work w;
   int which;
-  CHMC_HD void operator()(int tid) const {
-    const int c = tid / sy.Q;
-    if (!w.ok[c]) return;
+  CHMC_HD bool active(int c) const { return w.ok[c] != 0; }
+  CHMC_HD void operator()(int c, int col) const {  // row launch: components col, col + 1 of chain c
     const int s = sl.cur[c] ^ which;
-    const double qp = pick(sl.q, s ^ 1)[tid], qn = pick(sl.q, s)[tid], pn = pick(sl.p, s)[tid];
-    double sc, flow;
+    const size_t i = (size_t)c * sy.Q + col;
+    const bool two = col + 1 < sy.Q, wide = two && !(sy.Q & 1);
+    const double2_ qp = ldv2(pick(sl.q, s ^ 1) + i, wide, two), qn = ldv2(pick(sl.q, s) + i, wide, two);
+    const double2_ pn = ldv2(pick(sl.p, s) + i, wide, two), gr = ldv2(pick(sl.grad, s) + i, wide, two);
+    double sc;
+    double2_ flow, po, go;
     if (sy.gaussian) {
       sc = w.cdt[c] / w.sdt[c];
-      flow = (qp + w.sdt[c] * pn) / w.cdt[c];
+      flow.x = (qp.x + w.sdt[c] * pn.x) / w.cdt[c], flow.y = (qp.y + w.sdt[c] * pn.y) / w.cdt[c];
     } else {
       sc = 1.0 / w.dt[c];
-      flow = qp + w.dt[c] * pn;
+      flow.x = qp.x + w.dt[c] * pn.x, flow.y = qp.y + w.dt[c] * pn.y;
     }
-    pick(sl.p, s)[tid] = pn - sc * (flow - qn);
-    pick(sl.pg, s)[tid] = pick(sl.grad, s)[tid] + (sy.gaussian ? 0.0 : qn);
+    po.x = pn.x - sc * (flow.x - qn.x), po.y = pn.y - sc * (flow.y - qn.y);
+    go.x = gr.x + (sy.gaussian ? 0.0 : qn.x), go.y = gr.y + (sy.gaussian ? 0.0 : qn.y);
+    stv2(pick(sl.p, s) + i, po, wide, two);
+    stv2(pick(sl.pg, s) + i, go, wide, two);
   }
 };
 // KKickPg into the other slot followed by KFlow from there, in one pass (tangent momentum at the start of a step)
@@ -1712,24 +1744,26 @@ struct KKickFlowPg {
   Slots sl;
   Work w;
   double hfrac;
-  CHMC_HD void operator()(int tid) const {
-    const int c = tid / sy.Q;
-    if (!w.ok[c]) return;
+  CHMC_HD bool active(int c) const { return w.ok[c] != 0; }
+  CHMC_HD void operator()(int c, int col) const {  // row launch: components col, col + 1 of chain c
     const int s = sl.cur[c];
     const double h = hfrac * w.dt[c];
-    const double q0 = pick(sl.q, s)[tid];
-    const double p0 = pick(sl.p, s)[tid] - h * pick(sl.pg, s)[tid];
-    double qn, pn;
+    const size_t i = (size_t)c * sy.Q + col;
+    const bool two = col + 1 < sy.Q, wide = two && !(sy.Q & 1);
+    const double2_ q0 = ldv2(pick(sl.q, s) + i, wide, two), pp = ldv2(pick(sl.p, s) + i, wide, two);
+    const double2_ g = ldv2(pick(sl.pg, s) + i, wide, two);
+    double2_ p0, qn, pn;
+    p0.x = pp.x - h * g.x, p0.y = pp.y - h * g.y;
     if (sy.gaussian) {
       const double sn = w.sdt[c], cs = w.cdt[c];
-      qn = q0 * cs + sn * p0;
-      pn = p0 * cs - sn * q0;
+      qn.x = q0.x * cs + sn * p0.x, qn.y = q0.y * cs + sn * p0.y;
+      pn.x = p0.x * cs - sn * q0.x, pn.y = p0.y * cs - sn * q0.y;
     } else {
-      qn = q0 + w.dt[c] * p0;
+      qn.x = q0.x + w.dt[c] * p0.x, qn.y = q0.y + w.dt[c] * p0.y;
       pn = p0;
     }
-    pick(sl.q, s ^ 1)[tid] = qn;
-    pick(sl.p, s ^ 1)[tid] = pn;
+    stv2(pick(sl.q, s ^ 1) + i, qn, wide, two);
+    stv2(pick(sl.p, s ^ 1) + i, pn, wide, two);
   }
 };
 // reverse check distance max |q_back - q_start| (mici maximum_norm); column-max kernel, two components per work item
@@ -1744,7 +1778,7 @@ struct KRevDiff {
     const size_t i = (size_t)c * sy.Q + col;
     const double* qs = pick(sl.q, sl.cur[c]);
     if (col + 1 < sy.Q && (sy.Q & 1) == 0) {
-      const double2_ a = *reinterpret_cast<const double2_*>(w.qb + i), b = *reinterpret_cast<const double2_*>(qs + i);
+      const double2_ a = ld2_stream(w.qb + i), b = ld2_stream(qs + i);
       const unsigned long long u = absbits(a.x - b.x), v = absbits(a.y - b.y);
       return u > v ? u : v;
     }

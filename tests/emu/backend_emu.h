@@ -22,6 +22,14 @@ static void launch(F f, long n, int cls = 0) {
   for (long t = 0; t < n; ++t) f((int)t);
 }
 template <class F>
+static void launch_rows(F f, int ncol, int B, int cls = 0) {
+  (void)cls;
+  for (int c = 0; c < B; ++c) {
+    if (!f.active(c)) continue;
+    for (int col = 0; col < ncol; col += 2) f(c, col);
+  }
+}
+template <class F>
 static void launch_colmax(F f, int ncol, int B, int cls = 0) {
   (void)cls;
   for (int c = 0; c < B; ++c) {

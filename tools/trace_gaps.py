@@ -14,7 +14,7 @@ if mc:
     m["name"] = "memcpy:" + m["Direction"].astype(str)
     ev = pd.concat([ev, m[["Start_Timestamp", "End_Timestamp", "name"]]])
 ev = ev.sort_values("Start_Timestamp").reset_index(drop=True)
-idx = ev.index[ev["name"].str.contains("KBegin")].tolist()
+idx = ev.index[ev["name"].str.contains(r"KKickFlowPg|KKick>", regex=True)].tolist()  # first kernel of a leapfrog step
 s = idx[-nsteps]
 e = ev.index[ev["name"].str.contains("KCommit")].tolist()[-1]
 sub = ev.iloc[s:e + 1].copy()
