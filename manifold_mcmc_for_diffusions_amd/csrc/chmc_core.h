@@ -1778,7 +1778,7 @@ struct KRevDiff {
     const size_t i = (size_t)c * sy.Q + col;
     const double* qs = pick(sl.q, sl.cur[c]);
     if (col + 1 < sy.Q && (sy.Q & 1) == 0) {
-      const double2_ a = ld2_stream(w.qb + i), b = ld2_stream(qs + i);
+      const double2_ a = *reinterpret_cast<const double2_*>(w.qb + i), b = *reinterpret_cast<const double2_*>(qs + i);
       const unsigned long long u = absbits(a.x - b.x), v = absbits(a.y - b.y);
       return u > v ? u : v;
     }
