@@ -11,7 +11,7 @@ import sys
 import pandas as pd
 
 CLASS_OF = [  # substring of the kernel name -> profiling class of include/chmc.h
-    ("k_rev_wave<chmc::FhnModel, 7, 1>", "newton_blk"), ("k_rev_wave<chmc::FhnModel, 7, 0>", "state_blk"),
+    ("k_rev_wave<chmc::FhnModel, 7, 1", "newton_blk"), ("k_rev_wave<chmc::FhnModel, 7, 0", "state_blk"),
     ("k_gld_", "grad_log_det_blk"), ("KGldPrep", "sym_blk"), ("KUpdate", "update"), ("k_solve_chain_wave", "solve_chain"),
     ("k_jw_wave", "jacob_vec"), ("KFwd", "constr"), ("k_fwd_scan", "constr"), ("KKick", "elementwise"), ("KFlow", "elementwise"),
     ("KMomFix", "elementwise"), ("KRevDiff", "elementwise"), ("Factor", "sym_blk"), ("KSymBlk", "sym_blk"),
