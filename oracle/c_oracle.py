@@ -31,6 +31,8 @@ def lib():
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, dp]
         L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_set_metric.restype = C.c_int
+        L.orc_set_metric.argtypes = [C.c_void_p, dp]
         for f in ("orc_dim_q", "orc_num_partition", "orc_rmax", "orc_dim_nv"):
             getattr(L, f).restype = C.c_int
             getattr(L, f).argtypes = [C.c_void_p]
@@ -103,6 +105,15 @@ class OracleSystem:
         if getattr(self, "h", None):
             self.L.orc_destroy(self.h)
             self.h = None
+
+    def set_metric(self, M0):
+        """metric = blockdiag(M0 [U x U] dense positive definite, identity) (sde/mici_extensions.py:303-315); None: identity."""
+        rc = self.L.orc_set_metric(self.h, None if M0 is None else _d(_c(np.asarray(M0).reshape(self.U, self.U))))
+        if rc == -1:
+            raise ValueError("Only identity matrix metric can be used with Gaussian splitting")
+        if rc:
+            raise ValueError("M0 is not positive definite")
+        self.M0 = None if M0 is None else np.array(M0, dtype=np.float64).reshape(self.U, self.U)
 
     def dim_c(self, p):
         return self.L.orc_dim_c(self.h, p)

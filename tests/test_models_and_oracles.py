@@ -156,3 +156,71 @@ def test_linear_interpolation_initial_state():
     qh, xoh = find_initial_state_by_linear_interpolation(em.fhn, 0.2, 8, y, np.random.default_rng(9), gen, True)
     np.testing.assert_allclose(qh, rs.pos, atol=1e-11)
     np.testing.assert_allclose(xoh, rs.x_obs_seq, atol=0)
+
+
+def _spd(rng, n):
+    a = rng.standard_normal((n, n))
+    return a @ a.T / n + 0.5 * np.eye(n)
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy", [("fhn", 6, 4, 2, True), ("fhn", 7, 5, 3, False), ("sir", 5, 6, None, True)])
+def test_c_oracle_block_metric_against_dense_algebra(model, T, S, R, noisy):
+    """metric = blockdiag(M_0, I) (sde/mici_extensions.py:303-315, 794-798, 1033-1041, 1105-1113, 1202-1259): the oracle's
+    Woodbury pieces against dense linear algebra on the autodiff Jacobian."""
+    case = make_case(model, T, S, R, noisy, B=2, seed=31)
+    osy, rng = case["osys"], case["rng"]
+    ref = osys.make_system(omodels.MODELS[model], case["obs_interval"], S, R, case["y"][:, None], sigma=case["sigma"])
+    q, xo = case["q"][1], case["x_obs"][1]
+    M0 = _spd(rng, 4)
+    osy.set_metric(M0)
+    Minv = np.eye(osy.Q)
+    Minv[:4, :4] = np.linalg.inv(M0)
+    for part in range(osy.num_partition):
+        Jd = torch.func.jacrev(lambda qq: ref._constr(qq, osys.T(xo), part))(osys.T(q)).numpy()
+        G = Jd @ Minv @ Jd.T
+        w, lam = rng.standard_normal(osy.Q), rng.standard_normal(G.shape[0])
+        cC, _, ld, grad = osy.gram_ops(q, xo, part)
+        assert abs(ld - 0.5 * np.linalg.slogdet(G)[1]) < 1e-9
+        _, _, Gil, nsc = osy.jacob_products(q, xo, part, w, lam)
+        np.testing.assert_allclose(Gil, np.linalg.solve(G, lam), rtol=1e-7, atol=1e-9 * np.abs(Gil).max())
+        np.testing.assert_allclose(nsc, Jd.T @ np.linalg.solve(G, Jd @ Minv @ w), rtol=1e-7, atol=1e-9)
+        for _ in range(3):  # gradient of the log-determinant with the metric in the Gram matrix
+            d = rng.standard_normal(q.shape)
+            d /= np.linalg.norm(d)
+            fd = (osy.gram_ops(q + 1e-5 * d, xo, part, want_grad=False)[2]
+                  - osy.gram_ops(q - 1e-5 * d, xo, part, want_grad=False)[2]) / 2e-5
+            assert abs(fd - grad @ d) < 1e-6 * max(1.0, abs(fd))
+    # retraction: q' on the manifold, M (q_start - q') in the row space of the previous Jacobian, mu = M dq / dt
+    q0, x0 = case["q"][0], case["x_obs"][0]
+    Jp = torch.func.jacrev(lambda qq: ref._constr(qq, osys.T(x0), 0))(osys.T(q0)).numpy()
+    M = np.linalg.inv(Minv)
+    for newton in (True, False):
+        qs = q0 + 0.05 * Minv @ rng.standard_normal(osy.Q)
+        st, q1, mu, it, ndq, err = osy.project(newton, q0, qs, x0, 0, 0.05)
+        assert st == 0 and np.abs(osy.constr(q1, x0, 0)).max() < 1e-9
+        r = M @ (qs - q1)
+        np.testing.assert_allclose(mu * 0.05, r, rtol=1e-9, atol=1e-12)
+        coef = np.linalg.lstsq(Jp.T, r, rcond=None)[0]
+        assert np.abs(Jp.T @ coef - r).max() < 1e-9 * max(1.0, np.abs(r).max())
+    # one leapfrog step: tangent momentum, conserved constraint, reversibility, energy error O(dt^2)
+    ch = c_oracle.OracleChain(osy)
+    p = rng.standard_normal(osy.Q)
+    p[:4] = np.linalg.cholesky(M0) @ p[:4]  # metric.sqrt @ n (:1257)
+    ch.set(q0, p, x0, 0)
+    ch.project_mom()
+    _, p0, _, _ = ch.get()
+    assert np.abs(Jp @ Minv @ p0).max() < 1e-9 * np.abs(p0).max()
+    h0 = ch.hamiltonian()
+    st, itf, itb, rev = ch.step(0.02)
+    q1, p1, _, _ = ch.get()
+    assert st == 0 and np.abs(osy.constr(q1, x0, 0)).max() < 1e-9 and rev < 2e-8
+    J1 = torch.func.jacrev(lambda qq: ref._constr(qq, osys.T(x0), 0))(osys.T(q1)).numpy()
+    assert np.abs(J1 @ Minv @ p1).max() < 1e-8 * np.abs(p1).max()
+    assert abs(ch.hamiltonian() - h0) < 0.05 * max(1.0, abs(h0)) * 0.02
+    ch.set(q1, -p1, x0, 0)
+    st, _, _, _ = ch.step(0.02)
+    q2, p2, _, _ = ch.get()
+    assert st == 0 and np.abs(q2 - q0).max() < 1e-7 and np.abs(p2 + p0).max() < 1e-6 * max(1.0, np.abs(p0).max())
+    osy.set_metric(None)
+    with pytest.raises(ValueError):
+        make_case("fhn", 6, 4, 2, True, B=1, seed=1, gaussian=True)["osys"].set_metric(M0)
