@@ -76,6 +76,15 @@ int chmc_get_state(chmc_ctx* ctx, double* q, double* p, double* x_obs_seq, int* 
  * mom = 0, x_obs_seq = x_obs_seq_init and evaluates the state caches, like chmc_set_state. */
 int chmc_init_linear_interpolation(chmc_ctx* ctx, const double* u, const double* v_0, const double* x_obs_seq_init,
                                    int partition);
+/* system.metric = PositiveDefiniteBlockDiagonalMatrix((DensePositiveDefiniteMatrix(M_0), IdentityMatrix()))
+ * (sde/mici_extensions.py:279-315): M_0 [U][U] symmetric positive definite acts on the u-part of the state, the rest
+ * of the metric is the identity; NULL restores the identity metric.  Enters get_M_0_matrix (:794-798) in the Woodbury
+ * cores, log_det_sqrt_metric_0 (:305-310, :809), delta_q = metric.inv @ delta_mu in both solvers (:1033-1041,
+ * :1105-1113), h2 / dh2_dmom / h2_flow (:1202-1231), normal_space_component (:1243-1250) and sample_momentum
+ * (:1256-1259).  Refreshes the cached factors of the current state when one has been set; the momentum is kept as it
+ * is (project it again if it has to be tangent with respect to the new metric).  Errors: Gaussian splitting (the
+ * reference raises ValueError :293-300), M_0 not symmetric positive definite. */
+int chmc_set_metric(chmc_ctx* ctx, const double* M_0);
 int chmc_set_momentum(chmc_ctx* ctx, const double* p);
 int chmc_get_state_device(chmc_ctx* ctx, void* q_dev, void* p_dev);  /* device-to-device copies */
 int chmc_set_momentum_device(chmc_ctx* ctx, const void* p_dev);

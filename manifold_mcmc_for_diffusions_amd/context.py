@@ -91,6 +91,19 @@ class ChmcContext:
         check(self.L.chmc_get_state(self.h, ptr(q), ptr(p), ptr(xo), C.byref(part)), "chmc_get_state")
         return q, p, xo, part.value
 
+    def set_metric(self, M_0):
+        """metric = blockdiag(M_0 [U, U] dense positive definite, identity) (sde/mici_extensions.py:279-315); None = identity.
+        The cached factors of the current state are refreshed; the momentum is left as it is."""
+        if M_0 is None:
+            check(self.L.chmc_set_metric(self.h, None), "chmc_set_metric")
+            self.M_0 = None
+            return
+        m = np.ascontiguousarray(M_0, dtype=np.float64)
+        if m.shape != (self.U, self.U):
+            raise ValueError(f"M_0 must have shape ({self.U}, {self.U})")
+        check(self.L.chmc_set_metric(self.h, ptr(m)), "chmc_set_metric")
+        self.M_0 = m.copy()
+
     def set_momentum(self, p):
         p = self._bq(p, "p")
         check(self.L.chmc_set_momentum(self.h, ptr(p)), "chmc_set_momentum")

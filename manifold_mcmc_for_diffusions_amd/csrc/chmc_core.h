@@ -54,7 +54,25 @@ struct Sys {
   const BlockDesc* blk;
   const int* obs2blk;
   const int* order;  // [B * K] work item -> chain * K + block of the wave-per-block kernels (longest blocks first)
+  // metric M = diag(M_0, I) (:303-315): [3][U][U] = M_0, M_0^-1, lower Cholesky factor of M_0; nullptr = identity
+  const double* m0;
+  double hld_m0;  // log det(M_0) / 2 (log_det_sqrt_metric_0 :305-310)
 };
+// (M_0^-1 v_u)[a] and (M_0 v_u)[a] for the u-part of a [Q] vector (the rest of the metric is the identity)
+CHMC_HD inline double metric_inv_u(const Sys& sy, const double* vu, int a) {
+  if (!sy.m0) return vu[a];
+  const double* W = sy.m0 + sy.U * sy.U + a * sy.U;
+  double t = 0.0;
+  for (int b = 0; b < sy.U; ++b) t += W[b] * vu[b];
+  return t;
+}
+CHMC_HD inline double metric_mul_u(const Sys& sy, const double* vu, int a) {
+  if (!sy.m0) return vu[a];
+  const double* Mr = sy.m0 + a * sy.U;
+  double t = 0.0;
+  for (int b = 0; b < sy.U; ++b) t += Mr[b] * vu[b];
+  return t;
+}
 
 struct Slots {
   double* q[2];
@@ -730,7 +748,9 @@ struct KStateChain {
     double Cm[U * U];
     for (int i = 0; i < U * U; ++i) Cm[i] = 0.0;
     for (int i = 0; i < U; ++i) Cm[i * U + i] = 1.0;
-    double ld = 0.0;
+    if (sy.m0)  // get_M_0_matrix (:794-798)
+      for (int i = 0; i < U * U; ++i) Cm[i] = sy.m0[i];
+    double ld = sy.m0 ? -sy.hld_m0 : 0.0;  // - log_det_sqrt_metric_0 (:809)
     for (int b = 0; b < sy.K; ++b) {
       const double* Cb = w.Cb + ((size_t)c * sy.Kmax + b) * U * U;
       for (int i = 0; i < U * U; ++i) Cm[i] += Cb[i];
@@ -1257,6 +1277,8 @@ struct KSolveChain {
       int piv[U];
       for (int i = 0; i < U * U; ++i) Cm[i] = 0.0;
       for (int i = 0; i < U; ++i) Cm[i * U + i] = 1.0;
+      if (sy.m0)
+        for (int i = 0; i < U * U; ++i) Cm[i] = sy.m0[i];
       for (int b = 0; b < sy.K; ++b)
         for (int i = 0; i < U * U; ++i) Cm[i] += w.Cb[((size_t)c * sy.Kmax + b) * U * U + i];
       lu_factor<U>(Cm, piv);
@@ -1284,8 +1306,9 @@ struct KSolveChain {
       double* q = (qsel ? w.qb : pick(sl.q, s ^ 1)) + (size_t)c * sy.Q;
       unsigned long long nb = 0ULL;
       for (int a = 0; a < U; ++a) {
-        q[a] -= du[a];
-        unsigned long long vb = absbits(du[a]);
+        const double dq = metric_inv_u(sy, du, a);  // delta_q = metric.inv @ delta_mu (:1033-1041, :1105-1113)
+        q[a] -= dq;
+        unsigned long long vb = absbits(dq);
         if (vb > nb) nb = vb;
       }
       w.err[c] = bitsd(eb);
@@ -1575,7 +1598,7 @@ struct KJw {
   Sys sy;
   Slots sl;
   Work w;
-  int which, vsel;
+  int which, vsel_;  // vsel_ | 256: the vector is multiplied by metric.inv first
   CHMC_HD void operator()(int tid) const {
     const int i = tid % RM;
     const int cbk = tid / RM;
@@ -1584,12 +1607,14 @@ struct KJw {
     if (!w.ok[c]) return;
     const BlockDesc bd = sy.blk[b];
     const int s = sl.cur[c] ^ which;
+    const bool minv = (vsel_ & 256) != 0;  // J (metric.inv @ vct) instead of J vct (:1243-1250)
+    const int vsel = vsel_ & 255;
     const double* vct = (vsel == 0 ? pick(sl.p, s) : vsel == 1 ? w.pb : vsel == 2 ? w.vin : vsel == 4 ? pick(sl.pg, s) : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
     const size_t cb = (size_t)c * sy.Kmax + b;
     double acc = 0.0;
     if (i < bd.nrows) {
       const double* ju = pick(sl.JuP, s) + (cb * RM + i) * sy.U;
-      for (int a = 0; a < sy.U; ++a) acc += ju[a] * vct[a];
+      for (int a = 0; a < sy.U; ++a) acc += ju[a] * (minv ? metric_inv_u(sy, vct, a) : vct[a]);
       const double* Jv = pick(sl.Jv, s) + ((size_t)c * RM + i) * sy.NV + bd.col0;
       const double* wv = vct + sy.U + bd.col0;
       double a2 = 0.0;
@@ -1676,6 +1701,11 @@ struct KFlow {
       qn.x = q0.x + dt * p0.x, qn.y = q0.y + dt * p0.y;
       pn = p0;
     }
+    if (sy.m0 && col < sy.U) {  // pos += dt * metric.inv @ mom (:1208, :1231) on the u-part
+      const double* pu = (from_p_other ? pick(sl.p, s ^ 1) : pick(sl.p, s)) + (size_t)c * sy.Q;
+      qn.x = q0.x + dt * metric_inv_u(sy, pu, col);
+      if (col + 1 < sy.U) qn.y = q0.y + dt * metric_inv_u(sy, pu, col + 1);
+    }
     if (dst == 0) {
       stv2(pick(sl.q, s ^ 1) + i, qn, wide, two);
       // (standard splitting: the flow leaves the momentum as it is, and it already sits in the destination slot)
@@ -1734,6 +1764,24 @@ struct KMomFixInitPg {
     }
     po.x = pn.x - sc * (flow.x - qn.x), po.y = pn.y - sc * (flow.y - qn.y);
     go.x = gr.x + (sy.gaussian ? 0.0 : qn.x), go.y = gr.y + (sy.gaussian ? 0.0 : qn.y);
+    if (sy.m0 && col < sy.U) {
+      // Block metric, u-part (U even, <= 8: chmc_set_metric): the multiplier term is mu_u = M_0 (flow - q_new)_u with
+      // flow_u = q_prev_u + dt (M_0^-1 p)_u.  Every u-component needs all of p_u, which is updated in place, so the
+      // first work item of the row handles the whole u-part and the others leave it alone.
+      if (col != 0) return;
+      const size_t cq = (size_t)c * sy.Q;
+      const double* qpu = pick(sl.q, s ^ 1) + cq;
+      const double* qnu = pick(sl.q, s) + cq;
+      double* pu = pick(sl.p, s) + cq;
+      double mv[8], pnew[8];
+      for (int a = 0; a < sy.U; ++a) mv[a] = qpu[a] + w.dt[c] * metric_inv_u(sy, pu, a) - qnu[a];
+      for (int a = 0; a < sy.U; ++a) pnew[a] = pu[a] - sc * metric_mul_u(sy, mv, a);
+      for (int a = 0; a < sy.U; ++a) {
+        pu[a] = pnew[a];
+        pick(sl.pg, s)[cq + a] = pick(sl.grad, s)[cq + a] + qnu[a];
+      }
+      return;
+    }
     stv2(pick(sl.p, s) + i, po, wide, two);
     stv2(pick(sl.pg, s) + i, go, wide, two);
   }
@@ -1761,6 +1809,18 @@ struct KKickFlowPg {
     } else {
       qn.x = q0.x + w.dt[c] * p0.x, qn.y = q0.y + w.dt[c] * p0.y;
       pn = p0;
+    }
+    if (sy.m0 && col < sy.U) {  // u-part of the flow with the block metric: q_u += dt * M_0^-1 (p - h pg)_u
+      const double* pu = pick(sl.p, s) + (size_t)c * sy.Q;
+      const double* gu = pick(sl.pg, s) + (size_t)c * sy.Q;
+      double t0 = 0.0, t1 = 0.0;
+      for (int b = 0; b < sy.U; ++b) {
+        const double pb = pu[b] - h * gu[b];
+        t0 += sy.m0[sy.U * sy.U + col * sy.U + b] * pb;
+        if (col + 1 < sy.U) t1 += sy.m0[sy.U * sy.U + (col + 1) * sy.U + b] * pb;
+      }
+      qn.x = q0.x + w.dt[c] * t0;
+      if (col + 1 < sy.U) qn.y = q0.y + w.dt[c] * t1;
     }
     stv2(pick(sl.q, s ^ 1) + i, qn, wide, two);
     stv2(pick(sl.p, s ^ 1) + i, pn, wide, two);
@@ -1840,6 +1900,20 @@ struct KNormPart {
     w.part[((size_t)c * npart + j) * 2 + 1] = pp;
   }
 };
+// sample_momentum with the block metric: mom = metric.sqrt @ n (:1257), i.e. the u-part becomes chol(M_0) n_u
+struct KMetricSqrtU {
+  Sys sy;
+  Slots sl;
+  CHMC_HD void operator()(int c) const {
+    double* pu = pick(sl.p, sl.cur[c]) + (size_t)c * sy.Q;
+    const double* L = sy.m0 + 2 * sy.U * sy.U;
+    for (int a = sy.U - 1; a >= 0; --a) {  // lower triangular: row a only needs entries <= a, so go bottom-up in place
+      double t = 0.0;
+      for (int b = 0; b <= a; ++b) t += L[a * sy.U + b] * pu[b];
+      pu[a] = t;
+    }
+  }
+};
 struct KHamiltonian {
   Sys sy;
   Slots sl;
@@ -1850,6 +1924,10 @@ struct KHamiltonian {
     double qq = 0.0, pp = 0.0;
     for (int j = 0; j < npart; ++j) qq += w.part[((size_t)c * npart + j) * 2], pp += w.part[((size_t)c * npart + j) * 2 + 1];
     const double ld = sl.logdet[sl.cur[c]][c];
+    if (sy.m0) {  // h2 = mom @ metric.inv @ mom / 2 (:1202): the u-part's quadratic form replaces its plain square
+      const double* pu = pick(sl.p, sl.cur[c]) + (size_t)c * sy.Q;
+      for (int a = 0; a < sy.U; ++a) pp += pu[a] * (metric_inv_u(sy, pu, a) - pu[a]);
+    }
     out[c * 3 + 1] = 0.5 * qq;
     out[c * 3 + 2] = 0.5 * pp;
     out[c * 3] = 0.5 * qq + ld + 0.5 * pp;  // h1 + h2 is the same sum for both splittings

@@ -583,7 +583,9 @@ __global__ void __launch_bounds__(256) k_nld_grad_wave(Sys sy, const double* qin
 // dc/dn terms.  Result in work.cpad.
 // TWO: a second vector (the slot's pg) shares the pass over the stored rows; its result goes to work.cpad2.
 template <int RM, bool TWO = false>
-__global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int which, int vsel) {
+__global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int which, int vsel_) {
+  const bool minv = (vsel_ & 256) != 0;  // J (metric.inv @ vct): only the u-part of the block metric is not the identity
+  const int vsel = vsel_ & 255;
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= sy.B * sy.K) return;
@@ -669,10 +671,10 @@ __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int w
       if (k == i) a = acc[k], a2 = acc2[k];
     if (i < bd.nrows) {
       const double* ju = pick(sl.JuP, s) + (cb * RM + i) * sy.U;
-      for (int d = 0; d < sy.U; ++d) a += ju[d] * vct[d];
+      for (int d = 0; d < sy.U; ++d) a += ju[d] * (minv ? metric_inv_u(sy, vct, d) : vct[d]);
       if (sy.noisy && i < bd.ny) a += sy.sigma * vct[sy.U + sy.NV + bd.obs0 + i];
       if (TWO) {
-        for (int d = 0; d < sy.U; ++d) a2 += ju[d] * vct2[d];
+        for (int d = 0; d < sy.U; ++d) a2 += ju[d] * (minv ? metric_inv_u(sy, vct2, d) : vct2[d]);
         if (sy.noisy && i < bd.ny) a2 += sy.sigma * vct2[sy.U + sy.NV + bd.obs0 + i];
       }
     } else {
@@ -1197,7 +1199,7 @@ __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work
       double v = Cm[i];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      Cm[i] = v + ((i / U == i % U) ? 1.0 : 0.0);  // + M_0 = I
+      Cm[i] = v + (sy.m0 ? sy.m0[i] : ((i / U == i % U) ? 1.0 : 0.0));  // + M_0 (:794-798)
     }
     int piv[U];
     lu_factor<U>(Cm, piv);
@@ -1244,8 +1246,9 @@ __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work
       unsigned long long nb = 0ULL;
 #pragma unroll
       for (int a = 0; a < U; ++a) {
-        q[a] -= du[a];
-        const unsigned long long vb = absbits(du[a]);
+        const double dq = metric_inv_u(sy, du, a);  // delta_q = metric.inv @ delta_mu (:1033-1041, :1105-1113)
+        q[a] -= dq;
+        const unsigned long long vb = absbits(dq);
         nb = vb > nb ? vb : nb;
       }
       w.err[c] = bitsd(eb);

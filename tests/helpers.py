@@ -135,3 +135,52 @@ def check_steps_against_oracle(ctx, case, dts, newton=True, n_steps=1, tol=1e-9,
             assert abs(h1[c, 0] - chains[c].hamiltonian()) <= 1e-9 * max(1.0, abs(h1[c, 0]))
             out.append((st, itf, itb))
     return out
+
+
+def random_metric(rng, n=4):
+    a = rng.standard_normal((n, n))
+    return a @ a.T / n + 0.5 * np.eye(n)
+
+
+def check_block_metric_against_oracle(ctx, case, newton, dts, n_steps=2, tol=1e-9):
+    """metric = blockdiag(M_0, I) (sde/mici_extensions.py:279-315): per-op entry points, the retraction's multiplier
+    output, momentum sampling and fused leapfrog steps against the C oracle with the same M_0."""
+    from test_rng import reference_normals
+    osys, rng, B = case["osys"], case["rng"], case["B"]
+    M0 = random_metric(rng)
+    osys.set_metric(M0)
+    try:
+        ctx.set_metric(M0)
+        worst = check_ops_against_oracle(ctx, case)  # Woodbury cores, log-det (- log det M_0 / 2), gradient, normal space
+        # projection from a flowed point: position, multiplier term mu = M dq / dt, iteration counts
+        q0, x0 = case["q"][0], case["x_obs"][0]
+        qq, xx = np.repeat(q0[None], B, 0), np.repeat(x0[None], B, 0)
+        ctx.set_state(qq, None, xx, 0)
+        mv = 0.03 * rng.standard_normal((B, ctx.Q))
+        mv[:, :4] = mv[:, :4] @ np.linalg.inv(M0).T
+        dt = np.full(B, 0.05)
+        r = ctx.project(qq + mv, dt, newton=newton)
+        for c in range(B):
+            st, q1, mu, it, ndq, err = osys.project(newton, q0, qq[c] + mv[c], x0, 0, 0.05)
+            assert st == r["status"][c] == 0 and it == r["iters"][c]
+            np.testing.assert_allclose(r["q"][c], q1, rtol=0, atol=tol * max(1.0, np.abs(q1).max()))
+            np.testing.assert_allclose(r["mu"][c], mu, rtol=0, atol=1e-8 * max(1.0, np.abs(mu).max()))
+        # sample_momentum: metric.sqrt @ n, projected with J M^-1
+        ctx.sample_momentum(77, 2, 1)
+        _, p, _, _ = ctx.get_state()
+        Lc = np.linalg.cholesky(M0)
+        for c in range(B):
+            n = reference_normals(ctx.Q, c + 1, 77, 2)
+            n[:4] = Lc @ n[:4]
+            expect = n - osys.jacob_products(q0, x0, 0, n, np.zeros(ctx.dim_c))[3]
+            np.testing.assert_allclose(p[c], expect, rtol=1e-9, atol=1e-10)
+        # fused steps (tangent momenta: projected-kick shortcut; then from unprojected momenta)
+        for part in range(ctx.num_partition):
+            check_steps_against_oracle(ctx, case, dts, newton=newton, n_steps=n_steps, tol=tol, part=part)
+        check_steps_against_oracle(ctx, case, dts, newton=newton, n_steps=1, tol=tol, project=False)
+        # back to the identity: same results as a context that never had a metric
+        ctx.set_metric(None)
+    finally:
+        osys.set_metric(None)
+    check_ops_against_oracle(ctx, case)
+    return worst

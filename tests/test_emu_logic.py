@@ -167,3 +167,37 @@ def test_status_not_converged_matches_oracle(emu_lib):
 def test_status_non_reversible_matches_oracle(emu_lib):
     """reverse_check_tol below the round-off of the forward-backward retraction: NonReversibleStepError (mici)."""
     _status_case(emu_lib, dict(reverse_check_tol=1e-22), dict(rev_tol=1e-22), 3)
+
+
+METRIC_CASES = [("fhn", 6, 4, 2, True), ("fhn", 7, 5, 3, False), ("sir", 6, 8, 2, True), ("sir", 14, 6, 14, True),
+                ("fhn_nb", 6, 4, 2, True)]
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy", METRIC_CASES)
+@pytest.mark.parametrize("newton", [True, False])
+def test_block_metric(emu_lib, model, T, S, R, noisy, newton):
+    """M = blockdiag(M_0, I) on the u-part (sde/mici_extensions.py:279-315, 794-798, 1033-1041, 1105-1113, 1202-1259)."""
+    from helpers import check_block_metric_against_oracle
+    case = make_case(model, T, S, R, noisy, B=4, seed=41)
+    ctx = make_ctx(case)
+    check_block_metric_against_oracle(ctx, case, newton, np.array([0.05, -0.05, 0.08, 0.02]))
+    ctx.close()
+
+
+def test_block_metric_misuse(emu_lib):
+    case = make_case("fhn", 6, 4, 2, True, B=2, seed=42, gaussian=True)
+    ctx = make_ctx(case)
+    with pytest.raises(RuntimeError, match="Gaussian splitting"):
+        ctx.set_metric(np.eye(4) * 2.0)
+    ctx.close()
+    case = make_case("fhn", 6, 4, 2, True, B=2, seed=42)
+    ctx = make_ctx(case)
+    with pytest.raises(RuntimeError, match="positive definite"):
+        ctx.set_metric(-np.eye(4))
+    bad = np.eye(4)
+    bad[0, 1] = 0.3
+    with pytest.raises(RuntimeError, match="symmetric"):
+        ctx.set_metric(bad)
+    with pytest.raises(ValueError):
+        ctx.set_metric(np.eye(3))
+    ctx.close()

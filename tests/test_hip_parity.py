@@ -362,3 +362,16 @@ def test_unconstrained_hmc_target_matches_autodiff_oracle(model, T, S, gaussian)
         assert abs(val[c] - vo) <= 1e-10 * max(1.0, abs(vo))
         assert np.abs(g[c] - go).max() <= 1e-9 * max(1.0, np.abs(go).max())
     ctx.close()
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy", [("fhn", 6, 4, 2, True), ("fhn", 12, 16, 5, True), ("fhn", 7, 8, 3, False),
+                                               ("sir", 6, 8, 2, True), ("sir", 14, 6, 14, True), ("fhn_nb", 6, 4, 2, True)])
+@pytest.mark.parametrize("newton", [True, False])
+def test_block_metric(model, T, S, R, noisy, newton):
+    """M = blockdiag(M_0, I) on the u-part (sde/mici_extensions.py:279-315, 794-798, 1033-1041, 1105-1113, 1202-1259):
+    per-op entry points, retraction with its multiplier term, momentum sampling and fused steps against the oracle."""
+    from helpers import check_block_metric_against_oracle
+    case = make_case(model, T, S, R, noisy, B=4, seed=41)
+    ctx = make_ctx(case)
+    check_block_metric_against_oracle(ctx, case, newton, np.array([0.05, -0.05, 0.08, 0.02]))
+    ctx.close()
