@@ -11,9 +11,11 @@ from .errors import (ConvergenceError, NonReversibleStepError, IntegratorError, 
 from .context import ChmcContext  # noqa: F401
 from .system import (  # noqa: F401
     ConditionedDiffusionConstrainedSystem, ConditionedDiffusionHamiltonianState, SwitchPartitionTransition,
-    IdentityMatrix, jitted_solve_projection_onto_manifold_newton,
+    IdentityMatrix, DensePositiveDefiniteMatrix, PositiveDefiniteBlockDiagonalMatrix,
+    jitted_solve_projection_onto_manifold_newton,
     jitted_solve_projection_onto_manifold_quasi_newton, find_initial_state_by_linear_interpolation,
     conditioned_diffusion_neg_log_dens_and_grad)
 from .integrators import ConstrainedLeapfrogIntegrator  # noqa: F401
+from .adapters import OnlineBlockDiagonalMetricAdapter  # noqa: F401
 
 __version__ = "0.1.0"

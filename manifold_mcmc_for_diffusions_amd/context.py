@@ -32,6 +32,7 @@ class ChmcContext:
         d = np.zeros(16, dtype=np.int32)
         check(L.chmc_get_dims(h, iptr(d)), "chmc_get_dims")
         (self.B, self.Q, self.NV, self.U, self.X, self.T, self.S, self.num_partition, self.RM, self.Kmax) = map(int, d[:10])
+        self.M_0 = None  # block metric (set_metric); None = identity
         self.C = [int(d[10]), int(d[11])][: self.num_partition]
         self.K = [int(d[12]), int(d[13])][: self.num_partition]
         self.V, self.V0 = int(d[14]), int(d[15])

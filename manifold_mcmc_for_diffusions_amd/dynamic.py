@@ -80,6 +80,17 @@ class DynamicTransition:
     def _mask(self, m):
         return self.torch.from_numpy(np.ascontiguousarray(m)).to(self.dev)
 
+    def _dot(self, edge, span):
+        """dh_dmom(edge) . span per chain: dh_dmom = metric.inv @ mom (sde/mici_extensions.py:1204-1208); with the block
+        metric only the u-part differs from the plain inner product."""
+        d = (edge * span).sum(1)
+        M0 = getattr(self.ctx, "M_0", None)
+        if M0 is not None:
+            U = M0.shape[0]
+            Wm = self.torch.from_numpy(np.linalg.inv(M0) - np.eye(U)).to(self.dev)
+            d = d + ((edge[:, :U] @ Wm) * span[:, :U]).sum(1)
+        return d
+
     def sample(self, it):
         torch, ctx = self.torch, self.ctx
         B = ctx.B
@@ -147,7 +158,7 @@ class DynamicTransition:
                     turning = torch.zeros(B, dtype=torch.bool, device=self.dev)
                     for i in range(hi, lo - 1, -1):
                         span = self.sub_sum - self.ck_sum[i] + self.ck_p[i]
-                        turning |= ((self.ck_p[i] * span).sum(1) < 0) | ((self.p * span).sum(1) < 0)
+                        turning |= (self._dot(self.ck_p[i], span) < 0) | (self._dot(self.p, span) < 0)
                     turn = run & turning.cpu().numpy()
                     alive &= ~turn
                     run &= ~turn
@@ -168,8 +179,8 @@ class DynamicTransition:
             self.pos_p.copy_(torch.where(fm, self.p, self.pos_p))
             self.neg_q.copy_(torch.where(bm, self.q, self.neg_q))
             self.neg_p.copy_(torch.where(bm, self.p, self.neg_p))
-            # no-U-turn criterion on the whole tree (riemannian_no_u_turn_criterion with the identity metric)
-            turn = (((self.neg_p * self.sum_mom).sum(1) < 0) | ((self.pos_p * self.sum_mom).sum(1) < 0)).cpu().numpy()
+            # no-U-turn criterion on the whole tree (riemannian_no_u_turn_criterion: dh_dmom(edge) . sum of momenta)
+            turn = ((self._dot(self.neg_p, self.sum_mom) < 0) | (self._dot(self.pos_p, self.sum_mom) < 0)).cpu().numpy()
             alive &= ~(done & turn)
         # leave the selected positions on the context (every chain: the context may sit on a tree edge)
         self._sync()

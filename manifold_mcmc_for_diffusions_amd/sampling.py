@@ -50,7 +50,7 @@ def _mean_over_all_chains(local_sum, local_count):
 
 def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_adapt=0, solver=None, rng=None,
                        n_head=6, callback=None, trace_dir=None, trace_func=None, total_chains=None,
-                       jitter_length=False):
+                       jitter_length=False, metric_adapter=None, metric_window=0.75):
     """Runs n_iter transitions on all chains of `ctx`; returns traces of the first `n_head` position components
     ([n_iter, B, n_head]), accept statistics and the step size used.  Directions are sampled per chain and
     transition (forward / backward in time), failed trajectories are rejected.
@@ -64,7 +64,11 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
     jitter_length: every chain draws its number of leapfrog steps uniformly from 1..n_step per transition (a mixture
     of reversible kernels, so still a valid sampler); chains in regions where the retraction often fails then still
     move with their short trajectories instead of rejecting every long one (Mici's dynamic transition gets the same
-    effect by ending a trajectory at the failing step)."""
+    effect by ending a trajectory at the failing step).
+    metric_adapter: an `adapters.OnlineBlockDiagonalMetricAdapter` over the `dim_u` global parameters (standard
+    splitting only).  It sees the draws of the first `metric_window` of the warm-up; the block metric it produces
+    (per-chain statistics combined over all chains and ranks) is installed with `ctx.set_metric` there, and the
+    remaining warm-up transitions re-tune the step size for the new metric."""
     solver = dict(newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10, max_iters=50,
                   reverse_check_tol=2e-8) if solver is None else solver
     rng = np.random.default_rng(seed) if rng is None else rng
@@ -76,6 +80,12 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
             return rng.random(B)
         return rng.random(total_chains)[chain_offset:chain_offset + B]
 
+    n_metric, metric_state = 0, None
+    if metric_adapter is not None and n_adapt > 0:
+        if metric_adapter.dim_param != ctx.U:
+            raise ValueError(f"the block metric covers the dim_u = {ctx.U} global parameters")
+        n_metric = max(2, int(metric_window * n_adapt))
+        n_head = max(n_head, ctx.U)
     stuck = np.zeros(B, dtype=np.int64)  # consecutive trajectories with zero acceptance probability
     heads = np.empty((n_iter, B, n_head))
     acc_hist, eps_hist, fail_hist = np.empty(n_iter), np.empty(n_iter), np.empty(n_iter)
@@ -117,6 +127,14 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
             if writer is None:
                 writer = TraceWriter(trace_dir, B, n_iter, {k: v.shape[1:] for k, v in vals.items()})
             writer.write(it, vals)
+        if n_metric and it < n_metric:
+            if metric_state is None:
+                metric_state = metric_adapter.initialize(np.zeros((B, ctx.Q)))
+            metric_adapter.update(metric_state, heads[it])
+            if it == n_metric - 1:
+                metric = metric_adapter.finalize(metric_state)
+                ctx.set_metric(metric.blocks[0].array)
+                adapter = DualAveragingStepSize(step_size)  # the step size is re-tuned under the new metric
         acc_all = _mean_over_all_chains(prob.sum(), B)
         acc_hist[it], eps_hist[it], fail_hist[it] = acc_all, step_size, 1.0 - act.mean()
         if adapter is not None and it < n_adapt:
@@ -126,6 +144,8 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
         if callback is not None:
             callback(it, heads[it], prob.mean(), step_size)
     out = dict(heads=heads, accept_stat=acc_hist, step_size=eps_hist, fail_rate=fail_hist, final_step_size=step_size)
+    if n_metric:
+        out["metric_M_0"] = None if ctx.M_0 is None else ctx.M_0.copy()
     if writer is not None:
         import time
         from .traces import save_summary

@@ -20,7 +20,10 @@ _tokens = itertools.count(1)
 
 
 class IdentityMatrix:
-    """Stand-in for mici.matrices.IdentityMatrix (the only metric the device path implements)."""
+    """Stand-in for mici.matrices.IdentityMatrix."""
+
+    def __init__(self, size=None):
+        self.size = size
 
     def __matmul__(self, other):
         return other
@@ -36,6 +39,87 @@ class IdentityMatrix:
     def sqrt(self):
         return self
 
+    log_abs_det = 0.0
+
+
+class DensePositiveDefiniteMatrix:
+    """Stand-in for mici.matrices.DensePositiveDefiniteMatrix: `.array`, `.inv`, `.sqrt` (lower Cholesky factor),
+    `.log_abs_det`, `@` on the last axis of an array."""
+
+    def __init__(self, array):
+        self.array = np.array(array, dtype=np.float64)
+        if self.array.ndim != 2 or self.array.shape[0] != self.array.shape[1]:
+            raise ValueError("array must be square")
+        self._chol = np.linalg.cholesky(self.array)  # raises LinAlgError if not positive definite
+
+    @property
+    def shape(self):
+        return self.array.shape
+
+    def __matmul__(self, other):
+        return np.asarray(other) @ self.array.T
+
+    @property
+    def inv(self):
+        return DensePositiveDefiniteMatrix(np.linalg.inv(self.array))
+
+    @property
+    def sqrt(self):
+        return _Dense(self._chol)
+
+    @property
+    def log_abs_det(self):
+        return 2.0 * float(np.log(np.diag(self._chol)).sum())
+
+
+class _Dense:
+    def __init__(self, array):
+        self.array = array
+
+    def __matmul__(self, other):
+        return np.asarray(other) @ self.array.T
+
+
+class PositiveDefiniteBlockDiagonalMatrix:
+    """Stand-in for mici.matrices.PositiveDefiniteBlockDiagonalMatrix; the system accepts two blocks, a dense
+    positive-definite `dim_u x dim_u` one and an identity (sde/mici_extensions.py:279-315)."""
+
+    def __init__(self, blocks):
+        self.blocks = tuple(blocks)
+
+    def _apply(self, which, other):
+        other = np.asarray(other)
+        out, o = [], 0
+        for i, b in enumerate(self.blocks):
+            n = b.shape[0] if hasattr(b, "shape") else (other.shape[-1] - o if i == len(self.blocks) - 1 else b.size)
+            part = other[..., o:o + n]
+            out.append(part if _is_identity(b) else getattr(b, which) @ part if which else b @ part)
+            o += n
+        return np.concatenate(out, -1)
+
+    def __matmul__(self, other):
+        return self._apply("", other)
+
+    @property
+    def inv(self):
+        return _BlockOp(self, "inv")
+
+    @property
+    def sqrt(self):
+        return _BlockOp(self, "sqrt")
+
+    @property
+    def log_abs_det(self):
+        return float(sum(b.log_abs_det for b in self.blocks))
+
+
+class _BlockOp:
+    def __init__(self, m, which):
+        self.m, self.which = m, which
+
+    def __matmul__(self, other):
+        return self.m._apply(self.which, other)
+
 
 class ScaledIdentity:
     """`scalar * IdentityMatrix()` as returned by dh2_flow_dmom (:1233-1238)."""
@@ -48,8 +132,31 @@ class ScaledIdentity:
         return (s[..., None] if s.ndim else s) * other
 
 
+class _ScaledOp:
+    """`dt * metric.inv` (dh2_flow_dmom :1238)."""
+
+    def __init__(self, scalar, op):
+        self.scalar, self.op = scalar, op
+
+    def __matmul__(self, other):
+        s = np.asarray(self.scalar)
+        return (s[..., None] if s.ndim else s) * (self.op @ other)
+
+
 def _is_identity(metric):
     return metric is None or isinstance(metric, IdentityMatrix) or type(metric).__name__ == "IdentityMatrix"
+
+
+def _metric_m0(metric, dim_u):
+    """M_0 of a supported metric (None for the identity); raises as the reference does (:305-315)."""
+    if _is_identity(metric):
+        return None
+    blocks = getattr(metric, "blocks", None)
+    if blocks is not None and len(blocks) == 2 and _is_identity(blocks[1]) and hasattr(blocks[0], "array"):
+        m0 = np.asarray(blocks[0].array, dtype=np.float64)
+        if m0.shape == (dim_u, dim_u):
+            return m0
+    raise NotImplementedError("Only identity and block diagonal metrics with identity lower right block currently supported.")
 
 
 class ConditionedDiffusionHamiltonianState:
@@ -97,8 +204,7 @@ class ConditionedDiffusionConstrainedSystem:
         model = forward_func.model
         if use_gaussian_splitting and not _is_identity(metric):  # :293-300
             raise ValueError("Only identity matrix metric can be used with Gaussian splitting")
-        if not _is_identity(metric):  # :305-315 (block metrics are not implemented on the device path)
-            raise NotImplementedError("Only the identity metric is implemented on the device path.")
+        m0 = _metric_m0(metric, dim_u)  # :305-315
         if generate_σ is not None and not isinstance(generate_σ, Number):
             raise NotImplementedError("Variable observation noise (callable generate_σ) is not implemented; pass the "
                                       "fixed standard deviation as a number or None for noiseless observations.")
@@ -108,7 +214,7 @@ class ConditionedDiffusionConstrainedSystem:
         dim_v_0 = dim_x if dim_v_0 is None else dim_v_0
         if (dim_u, dim_x, dim_v, dim_v_0) != (model.dim_z, model.dim_x, model.dim_v, model.dim_v_0):
             raise ValueError("dim_u / dim_x / dim_v / dim_v_0 do not match the model")
-        self.metric = IdentityMatrix()
+        self._metric = IdentityMatrix()
         self.use_gaussian_splitting = bool(use_gaussian_splitting)
         self.model = model
         self.ctx = ChmcContext(model.name, obs_interval, num_steps_per_obs, num_obs_per_subseq, y_seq[:, 0],
@@ -125,6 +231,21 @@ class ConditionedDiffusionConstrainedSystem:
         self.y_subseqs = [[y_seq[b["obs0"]:b["obs0"] + b["nobs"]] for b in blocks] for blocks in self.ctx.blocks]
         self._resident = None
         self._resident_mom = None
+        if m0 is not None:
+            self.metric = metric
+
+    @property
+    def metric(self):
+        return self._metric
+
+    @metric.setter
+    def metric(self, metric):  # assigned by metric adapters at the end of the warm-up (:1926-1931)
+        m0 = _metric_m0(metric, self.model_dict["dim_u"])
+        if m0 is not None and self.use_gaussian_splitting:
+            raise ValueError("Only identity matrix metric can be used with Gaussian splitting")
+        self.ctx.set_metric(m0)
+        self._metric = IdentityMatrix() if m0 is None else metric
+        self._resident = self._resident_mom = None  # the cached factors depend on the metric
 
     # ---- residency (plays the role of cache_in_state)
     def _b(self, a, tail):
@@ -195,13 +316,13 @@ class ConditionedDiffusionConstrainedSystem:
     def h2(self, state):  # :1198-1202
         if self.use_gaussian_splitting:
             return 0.5 * np.sum(state.pos ** 2, -1) + 0.5 * np.sum(state.mom ** 2, -1)
-        return 0.5 * np.sum(state.mom ** 2, -1)
+        return 0.5 * np.sum(state.mom * (self.metric.inv @ state.mom), -1)
 
     def h(self, state):
         return self.h1(state) + self.h2(state)
 
     def dh2_dmom(self, state):  # :1204-1208
-        return state.mom
+        return self.metric.inv @ state.mom
 
     def dh_dmom(self, state):
         return self.dh2_dmom(state)
@@ -231,7 +352,7 @@ class ConditionedDiffusionConstrainedSystem:
     def dh2_flow_dmom(self, dt):  # :1233-1238
         if self.use_gaussian_splitting:
             return ScaledIdentity(np.sin(dt)), ScaledIdentity(np.cos(dt))
-        return ScaledIdentity(dt), IdentityMatrix()
+        return (ScaledIdentity(dt) if _is_identity(self.metric) else _ScaledOp(dt, self.metric.inv)), IdentityMatrix()
 
     def update_x_obs_seq(self, state):  # :1240-1241
         self._sync(state)
@@ -249,7 +370,7 @@ class ConditionedDiffusionConstrainedSystem:
         return mom
 
     def sample_momentum(self, state, rng):  # :1256-1259
-        mom = rng.standard_normal(state.pos.shape)
+        mom = self.metric.sqrt @ rng.standard_normal(state.pos.shape)
         return self.project_onto_cotangent_space(mom, state)
 
 

@@ -32,9 +32,11 @@ def run(total, n_steps, rank, world):
     return local
 
 
-def run_sampler(total, n_iter, rank, world):
-    """Static-trajectory sampler with step-size adaptation on this rank's shard (cross-rank accept statistic)."""
+def run_sampler(total, n_iter, rank, world, metric=False):
+    """Static-trajectory sampler with step-size adaptation on this rank's shard (cross-rank accept statistic);
+    metric: also the block-diagonal metric adapter (per-chain statistics combined over the chains of all ranks)."""
     from manifold_mcmc_for_diffusions_amd.sampling import sample_static_chmc
+    from manifold_mcmc_for_diffusions_amd.adapters import OnlineBlockDiagonalMetricAdapter
     _lib._LIB = _lib._bind(ctypes.CDLL(os.path.join(HERE, "emu", "libchmc_emu.so")))
     T, S, R, sigma = 6, 4, 2, 0.1
     y = em.simulate_fhn_observations(T, 0.2, 50, seed=5, sigma=sigma)
@@ -42,17 +44,20 @@ def run_sampler(total, n_iter, rank, world):
     q, xo, _ = fhn_initial_states(em.fhn, 0.2, S, y, cnt, True, seed=7, chain_offset=off, total_chains=total)
     ctx = ChmcContext("fhn", 0.2, S, R, y[:, 0], sigma=sigma, num_chains=cnt)
     ctx.set_state(q, None, xo, 0)
-    res = sample_static_chmc(ctx, n_iter, 2, 0.05, seed=3, chain_offset=off, n_adapt=n_iter - 2, total_chains=total)
+    res = sample_static_chmc(ctx, n_iter, 2, 0.05, seed=3, chain_offset=off, n_adapt=n_iter - 2, total_chains=total,
+                             metric_adapter=OnlineBlockDiagonalMetricAdapter(4) if metric else None)
     ctx.close()
     hist = np.concatenate([res["step_size"], res["accept_stat"], [res["final_step_size"]]])
+    if metric:
+        hist = np.concatenate([hist, res["metric_M_0"].ravel()])
     return np.concatenate([res["heads"][-1], np.tile(hist, (cnt, 1))], 1)
 
 
 if __name__ == "__main__":
     out, total, n_steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     rank, _, world = D.init_process_group("gloo")
-    if len(sys.argv) > 4 and sys.argv[4] == "sampler":
-        local = run_sampler(total, n_steps, rank, world)
+    if len(sys.argv) > 4 and sys.argv[4] in ("sampler", "sampler_metric"):
+        local = run_sampler(total, n_steps, rank, world, metric=sys.argv[4] == "sampler_metric")
     else:
         local = run(total, n_steps, rank, world)
     gathered = D.gather_samples(local)

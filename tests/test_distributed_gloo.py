@@ -44,13 +44,14 @@ def test_two_ranks_equal_one_rank(emu_lib, tmp_path, total):  # noqa: F811
     np.testing.assert_array_equal(gathered, single)
 
 
-def test_two_ranks_adapt_one_step_size(emu_lib, tmp_path):  # noqa: F811
+@pytest.mark.parametrize("mode", ["sampler", "sampler_metric"])
+def test_two_ranks_adapt_one_step_size(emu_lib, tmp_path, mode):  # noqa: F811
     """Sampler with dual-averaging warm-up on two ranks: the accept statistic is combined over the chains of both
     ranks (one all-reduce per transition), so both ranks use the same step sizes, and with the chain-indexed random
     streams the sharded run reproduces the single-process run."""
     import dist_worker
-    total, n_iter = 4, 6
-    single = dist_worker.run_sampler(total, n_iter, 0, 1)
+    total, n_iter = (4, 6) if mode == "sampler" else (4, 10)
+    single = dist_worker.run_sampler(total, n_iter, 0, 1, metric=mode == "sampler_metric")
     out = str(tmp_path / "gathered.npy")
     port = free_port()
     procs = []
@@ -58,7 +59,7 @@ def test_two_ranks_adapt_one_step_size(emu_lib, tmp_path):  # noqa: F811
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dist_worker.py"), out, str(total),
-                                       str(n_iter), "sampler"], env=env, stdout=subprocess.PIPE,
+                                       str(n_iter), mode], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     for p in procs:
         try:

@@ -5,7 +5,14 @@ import numpy as np
 from test_emu_logic import emu_lib  # noqa: F401
 
 
-def _reference_transition(ctx1, q, p, xo, part, draw, eps, max_depth, max_delta_h, solver):
+def _reference_transition(ctx1, q, p, xo, part, draw, eps, max_depth, max_delta_h, solver, W=None):
+    def vel(pp):  # dh_dmom = metric.inv @ mom (sde/mici_extensions.py:1204-1208)
+        if W is None:
+            return pp
+        v = pp.copy()
+        v[:W.shape[0]] = W @ pp[:W.shape[0]]
+        return v
+
     def step(qv, pv, sgn):
         ctx1.set_state(qv[None], pv[None], xo[None], part)
         r = ctx1.leapfrog_step(np.array([sgn * eps]), **solver)
@@ -39,7 +46,7 @@ def _reference_transition(ctx1, q, p, xo, part, draw, eps, max_depth, max_delta_
             while (k + 1) % (1 << j) == 0 and (1 << j) <= (1 << d):  # aligned spans of 2^j leaves ending here
                 a = k + 1 - (1 << j)
                 span = sum(pp for _, pp in leaves[a:k + 1])
-                if leaves[a][1] @ span < 0 or leaves[k][1] @ span < 0:
+                if vel(leaves[a][1]) @ span < 0 or vel(leaves[k][1]) @ span < 0:
                     ok = False
                 j += 1
             if not ok:
@@ -54,12 +61,16 @@ def _reference_transition(ctx1, q, p, xo, part, draw, eps, max_depth, max_delta_
             pos = cur
         else:
             neg = cur
-        if neg[1] @ sum_mom < 0 or pos[1] @ sum_mom < 0:
+        if vel(neg[1]) @ sum_mom < 0 or vel(pos[1]) @ sum_mom < 0:
             break
     return prop, n_step
 
 
-def test_batched_tree_equals_single_chain_restatement(emu_lib):  # noqa: F811
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("with_metric", [False, True])
+def test_batched_tree_equals_single_chain_restatement(emu_lib, with_metric):  # noqa: F811
     from manifold_mcmc_for_diffusions_amd import example_models as em
     from manifold_mcmc_for_diffusions_amd.init import fhn_initial_states
     from manifold_mcmc_for_diffusions_amd.context import ChmcContext
@@ -72,6 +83,12 @@ def test_batched_tree_equals_single_chain_restatement(emu_lib):  # noqa: F811
     ctx1 = ChmcContext("fhn", 0.2, 4, 2, y[:, 0], sigma=0.1, num_chains=1)
     q, xo, _ = fhn_initial_states(em.fhn, 0.2, 4, y, B, True, seed=7)
     ctx.set_state(q, None, xo, 0)
+    W = None
+    if with_metric:  # block metric on the global parameters: enters the integrator and the no-U-turn criterion
+        a = np.random.default_rng(3).standard_normal((4, 4))
+        M0 = a @ a.T / 4 + 0.5 * np.eye(4)
+        ctx.set_metric(M0), ctx1.set_metric(M0)
+        W = np.linalg.inv(M0)
     tr = DynamicTransition(ctx, eps, seed=11, max_tree_depth=depth)
     n_total = 0
     for it in range(5):
@@ -82,7 +99,7 @@ def test_batched_tree_equals_single_chain_restatement(emu_lib):  # noqa: F811
         un = TreeUniforms(11, it, B, 0, B)
         for c in range(B):
             prop, n = _reference_transition(ctx1, q0[c], p0[c], xo0[c], part,
-                                            lambda kind, d, k, c=c: un.get(kind, d, k)[c], eps, depth, 1000.0, tr.solver)
+                                            lambda kind, d, k, c=c: un.get(kind, d, k)[c], eps, depth, 1000.0, tr.solver, W)
             assert n == st["n_step"][c], (it, c, n, st["n_step"][c])
             np.testing.assert_allclose(q1[c], prop, rtol=0, atol=1e-9)
             n_total += n

@@ -132,3 +132,56 @@ def test_batched_system(emu_lib):  # noqa: F811
     s1 = integ.step(st)
     assert s1.pos.shape == (3, sysm.ctx.Q) and (s1.step_status == 0).all()
     assert np.abs(sysm.constr(s1)).max() < 1e-9
+
+
+def test_block_metric_surface(emu_lib):  # noqa: F811
+    """metric = PositiveDefiniteBlockDiagonalMatrix((DensePositiveDefiniteMatrix(M_0), IdentityMatrix())) as the
+    reference accepts it (sde/mici_extensions.py:279-315), set at construction or assigned later (:1926-1931)."""
+    from oracle import c_oracle
+    _, sysm, _, st, rng = build_pair(True, False)
+    a = rng.standard_normal((4, 4))
+    M0 = a @ a.T / 4 + 0.5 * np.eye(4)
+    metric = mm.PositiveDefiniteBlockDiagonalMatrix((mm.DensePositiveDefiniteMatrix(M0), mm.IdentityMatrix()))
+    sysm.metric = metric
+    y = sysm.model_dict["y_seq"]
+    osy = c_oracle.OracleSystem("fhn", 0.2, 4, 2, y[:, 0], sigma=0.1)
+    osy.set_metric(M0)
+    st.mom = sysm.sample_momentum(st, np.random.default_rng(2))
+    n = np.random.default_rng(2).standard_normal(st.pos.shape)
+    n[:4] = np.linalg.cholesky(M0) @ n[:4]  # metric.sqrt @ n (:1257)
+    expect = n - osy.jacob_products(st.pos, st.x_obs_seq, st.partition, n, np.zeros(osy.dim_c(st.partition)))[3]
+    np.testing.assert_allclose(st.mom, expect, rtol=1e-9, atol=1e-10)
+    ch = c_oracle.OracleChain(osy)
+    ch.set(st.pos, st.mom, st.x_obs_seq, st.partition)
+    assert abs(sysm.h(st) - ch.hamiltonian()) < 1e-9 * max(1.0, abs(ch.hamiltonian()))
+    np.testing.assert_allclose(sysm.dh2_dmom(st)[:4], np.linalg.solve(M0, st.mom[:4]), rtol=1e-10)
+    np.testing.assert_allclose(sysm.dh2_dmom(st)[4:], st.mom[4:])
+    integ = mm.ConstrainedLeapfrogIntegrator(sysm, step_size=0.05, projection_solver_kwargs=TOLS)
+    new = integ.step(st)
+    stt, itf, itb, rev = ch.step(0.05)
+    qo, po, _, _ = ch.get()
+    assert stt == 0
+    np.testing.assert_allclose(new.pos, qo, rtol=0, atol=1e-9 * max(1.0, np.abs(qo).max()))
+    np.testing.assert_allclose(new.mom, po, rtol=0, atol=1e-9 * max(1.0, np.abs(po).max()))
+    # composed path (python-level A-B-A with the per-op entry points) agrees with the fused one
+    composed = mm.ConstrainedLeapfrogIntegrator(
+        sysm, step_size=0.05, projection_solver_kwargs=TOLS,
+        projection_solver=lambda *a, **k: mm.jitted_solve_projection_onto_manifold_newton(*a, **k))
+    b = composed.step(st)
+    np.testing.assert_allclose(b.pos, new.pos, rtol=0, atol=1e-10)
+    np.testing.assert_allclose(b.mom, new.mom, rtol=0, atol=1e-9)
+    # constructor argument, refusals of the reference
+    y2 = y
+    s2 = mm.ConditionedDiffusionConstrainedSystem(
+        0.2, 4, 2, y2, em.fhn.dim_z, em.fhn.dim_x, em.fhn.dim_v, em.fhn.forward_func, em.fhn.generate_x_0,
+        em.fhn.generate_z, em.fhn.obs_func, generate_σ=0.1, metric=metric, dim_v_0=em.fhn.dim_v_0)
+    assert s2.metric is metric and np.allclose(s2.ctx.M_0, M0)
+    with pytest.raises(ValueError):
+        mm.ConditionedDiffusionConstrainedSystem(
+            0.2, 4, 2, y2, em.fhn.dim_z, em.fhn.dim_x, em.fhn.dim_v, em.fhn.forward_func, em.fhn.generate_x_0,
+            em.fhn.generate_z, em.fhn.obs_func, generate_σ=0.1, metric=metric, use_gaussian_splitting=True,
+            dim_v_0=em.fhn.dim_v_0)
+    with pytest.raises(NotImplementedError):
+        sysm.metric = mm.DensePositiveDefiniteMatrix(np.eye(sysm.ctx.Q))
+    sysm.metric = None
+    assert isinstance(sysm.metric, mm.IdentityMatrix) and sysm.ctx.M_0 is None
