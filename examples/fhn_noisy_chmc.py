@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """End-to-end example on an MI355X: posterior sampling for the FitzHugh-Nagumo model with noisy observations
 (the configuration of scripts/fhn_model_noisy_obs_chmc_experiment.py in the reference: T = 100 observations,
-R = 5, sigma_y = 0.1) with batched constrained HMC.   usage: fhn_noisy_chmc.py [chains] [S] [iters] [warm-up] [output dir] [static|dynamic]
+R = 5, sigma_y = 0.1) with batched constrained HMC.   usage: fhn_noisy_chmc.py [chains] [S] [iters] [warm-up] [output dir] [static|dynamic|metric]
+`metric`: static trajectories with the block-diagonal metric adapter of the reference (sde/mici_extensions.py:1804-1931) on the
+four global parameters during the warm-up.
 With an output directory the traced variables of the reference's trace function (sigma, epsilon, gamma, beta, x_0,
 hamiltonian) are written as memory-mapped `.npy` files together with `summary.json`."""
 import os
@@ -20,6 +22,7 @@ n_iter = int(sys.argv[3]) if len(sys.argv) > 3 else 150
 n_warm = int(sys.argv[4]) if len(sys.argv) > 4 else 50
 out_dir = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "-" else None
 dynamic = len(sys.argv) > 6 and sys.argv[6] == "dynamic"  # the reference's transition (no-U-turn trees) instead of 16 fixed steps
+adapt_metric = len(sys.argv) > 6 and sys.argv[6] == "metric"
 
 
 def trace_func(head, ham):  # scripts/fhn_model_noisy_obs_chmc_experiment.py:82-99
@@ -41,7 +44,9 @@ if dynamic:
     res["fail_rate"] = res["integrator_error"]
     steps_total = float(res["n_step"].sum()) * B
 else:
+    from manifold_mcmc_for_diffusions_amd.adapters import OnlineBlockDiagonalMetricAdapter  # noqa: E402
     res = sample_static_chmc(wl.ctx, n_iter, 16, 0.1, seed=wl.seed, n_adapt=n_warm, trace_dir=out_dir, trace_func=trace_func,
+                             metric_adapter=OnlineBlockDiagonalMetricAdapter(4) if adapt_metric else None,
                              callback=lambda it, h, a, e: (it % 10 == 0) and print(
                                  f"  iter {it:4d} accept {a:.2f} step {e:.3f} z-median {np.median(em.fhn.generate_z(h[:, :4]), 0).round(3)}",
                                  flush=True))
@@ -51,6 +56,8 @@ z = em.fhn.generate_z(res["heads"][n_warm:, :, :4])  # [iters, B, 4] = sigma, ep
 x0 = em.fhn.generate_x_0(z, res["heads"][n_warm:, :, 4:6])
 print(f"{n_iter} transitions x {'dynamic trees' if dynamic else '16 steps'} x {B} chains in {el:.1f} s = {steps_total / el:.0f} leapfrog steps/s "
       f"(includes momentum refresh, accept/reject, partition switch, host traces)")
+if adapt_metric:
+    print("adapted M_0 (inverse of the regularised covariance of u over all chains):\n", np.round(res["metric_M_0"], 2))
 print("final step size", round(res["final_step_size"], 4), "mean accept (main)", res["accept_stat"][n_warm:].mean().round(3),
       "failed trajectories", res["fail_rate"][n_warm:].mean().round(4))
 names = ["sigma", "epsilon", "gamma", "beta"]

@@ -50,7 +50,7 @@ def _mean_over_all_chains(local_sum, local_count):
 
 def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_adapt=0, solver=None, rng=None,
                        n_head=6, callback=None, trace_dir=None, trace_func=None, total_chains=None,
-                       jitter_length=False, metric_adapter=None, metric_window=0.75):
+                       jitter_length=False, metric_adapter=None, metric_window=0.75, metric_skip=0.25):
     """Runs n_iter transitions on all chains of `ctx`; returns traces of the first `n_head` position components
     ([n_iter, B, n_head]), accept statistics and the step size used.  Directions are sampled per chain and
     transition (forward / backward in time), failed trajectories are rejected.
@@ -66,7 +66,8 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
     move with their short trajectories instead of rejecting every long one (Mici's dynamic transition gets the same
     effect by ending a trajectory at the failing step).
     metric_adapter: an `adapters.OnlineBlockDiagonalMetricAdapter` over the `dim_u` global parameters (standard
-    splitting only).  It sees the draws of the first `metric_window` of the warm-up; the block metric it produces
+    splitting only).  It sees the warm-up draws between the fractions `metric_skip` (the initial transient is left
+    out, like the first window of a staged warm-up) and `metric_window` of the warm-up; the block metric it produces
     (per-chain statistics combined over all chains and ranks) is installed with `ctx.set_metric` there, and the
     remaining warm-up transitions re-tune the step size for the new metric."""
     solver = dict(newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10, max_iters=50,
@@ -80,11 +81,12 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
             return rng.random(B)
         return rng.random(total_chains)[chain_offset:chain_offset + B]
 
-    n_metric, metric_state = 0, None
+    n_metric, n_skip, metric_state = 0, 0, None
     if metric_adapter is not None and n_adapt > 0:
         if metric_adapter.dim_param != ctx.U:
             raise ValueError(f"the block metric covers the dim_u = {ctx.U} global parameters")
         n_metric = max(2, int(metric_window * n_adapt))
+        n_skip = min(int(metric_skip * n_adapt), n_metric - 2)
         n_head = max(n_head, ctx.U)
     stuck = np.zeros(B, dtype=np.int64)  # consecutive trajectories with zero acceptance probability
     heads = np.empty((n_iter, B, n_head))
@@ -127,7 +129,7 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
             if writer is None:
                 writer = TraceWriter(trace_dir, B, n_iter, {k: v.shape[1:] for k, v in vals.items()})
             writer.write(it, vals)
-        if n_metric and it < n_metric:
+        if n_metric and n_skip <= it < n_metric:
             if metric_state is None:
                 metric_state = metric_adapter.initialize(np.zeros((B, ctx.Q)))
             metric_adapter.update(metric_state, heads[it])
