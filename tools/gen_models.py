@@ -128,8 +128,51 @@ class Hoister:
         return e.func(*[self.hoist(a) for a in e.args])
 
 
-def emit_assignments(lines, outputs, names, tmp_prefix="t"):
+def factor_state_exps(lines, outputs, nx):
+    """exp(sum_i c_i x[i]) with half-integer c_i (the log-transformed SIR state: every exponential of the step, its
+    Jacobian and its Hessian contraction is of this form) as a product of powers of e_i = exp(x[i] / 2) and
+    ie_i = 1 / e_i: one exponential per state component instead of one per distinct argument (ten in the SIR step;
+    a transcendental costs ~40 dependent fp64 instructions, which is what paces the sequential scans)."""
+    xs = [sp.Symbol("x[%d]" % i) for i in range(nx)]
+    atoms = set()
+    for e in outputs:
+        atoms |= e.atoms(sp.exp)
+    E = [sp.Symbol("e%d" % i, positive=True) for i in range(nx)]
+    IE = [sp.Symbol("ie%d" % i, positive=True) for i in range(nx)]
+    rep, need_e, need_ie = {}, set(), set()
+    for a in atoms:
+        arg = sp.expand(a.args[0])
+        if not arg.free_symbols or not arg.free_symbols <= set(xs):
+            continue
+        pol = sp.Poly(arg, *xs)
+        if pol.total_degree() != 1 or pol.coeff_monomial(1) != 0:
+            continue
+        co = [pol.coeff_monomial(x) for x in xs]
+        if not all((2 * c).is_Integer for c in co):
+            continue
+        term = sp.Integer(1)
+        for i, c in enumerate(co):
+            n = int(2 * c)
+            if n > 0:
+                term *= E[i] ** n
+                need_e.add(i)
+            elif n < 0:
+                term *= IE[i] ** (-n)
+                need_e.add(i), need_ie.add(i)
+        rep[a] = term
+    if len(rep) < 3:
+        return outputs
+    for i in sorted(need_e):
+        lines.append("  const double e%d = exp(0.5*x[%d]);" % (i, i))
+    for i in sorted(need_ie):
+        lines.append("  const double ie%d = 1.0/e%d;" % (i, i))
+    return [e.xreplace(rep) for e in outputs]
+
+
+def emit_assignments(lines, outputs, names, tmp_prefix="t", nx=0):
     """CSE `outputs` and append C statements to `lines`."""
+    if nx:
+        outputs = factor_state_exps(lines, list(outputs), nx)
     repl, red = sp.cse(list(outputs), symbols=sp.numbered_symbols(tmp_prefix), optimizations="basic")
     for s, e in repl:
         lines.append("  const double %s = %s;" % (s, cc(e)))
@@ -331,7 +374,7 @@ def gen_model(m):
     L.append("")
     # step
     L.append("CHMC_HD static inline void chmc_%s_step(const double* k, const double* x, const double* v, double* xn) {" % nm)
-    emit_assignments(L, [subs_arr(e) for e in f_h], ["xn[%d]" % i for i in range(X)])
+    emit_assignments(L, [subs_arr(e) for e in f_h], ["xn[%d]" % i for i in range(X)], nx=X)
     L.append("}")
     L.append("")
     # step + jac
@@ -339,7 +382,7 @@ def gen_model(m):
     outs = [subs_arr(e) for e in f_h + A_h + B_h + Z_h]
     names = (["xn[%d]" % i for i in range(X)] + ["A[%d]" % i for i in range(X * X)] +
              ["B[%d]" % i for i in range(X * V)] + ["Zf[%d]" % i for i in range(X * Z)])
-    emit_assignments(L, outs, names)
+    emit_assignments(L, outs, names, nx=X)
     L.append("}")
     L.append("")
     # jac only (no xn)
@@ -347,19 +390,19 @@ def gen_model(m):
     outs = [subs_arr(e) for e in A_h + B_h + Z_h]
     names = (["A[%d]" % i for i in range(X * X)] + ["B[%d]" % i for i in range(X * V)] +
              ["Zf[%d]" % i for i in range(X * Z)])
-    emit_assignments(L, outs, names)
+    emit_assignments(L, outs, names, nx=X)
     L.append("}")
     L.append("")
     # A and B only
     L.append("CHMC_HD static inline void chmc_%s_jac_ab(const double* k, const double* x, const double* v, double* A, double* B) {" % nm)
     outs = [subs_arr(e) for e in A_h + B_h]
     names = ["A[%d]" % i for i in range(X * X)] + ["B[%d]" % i for i in range(X * V)]
-    emit_assignments(L, outs, names)
+    emit_assignments(L, outs, names, nx=X)
     L.append("}")
     L.append("")
     # hess
     L.append("CHMC_HD static inline void chmc_%s_step_hess(const double* k, const double* x, const double* v, const double* S, double* out) {" % nm)
-    emit_assignments(L, [subs_arr(e) for e in H_h], ["out[%d]" % i for i in range(NXI)])
+    emit_assignments(L, [subs_arr(e) for e in H_h], ["out[%d]" % i for i in range(NXI)], nx=X)
     L.append("}")
     L.append("")
     # gz
