@@ -85,6 +85,19 @@ int chmc_init_linear_interpolation(chmc_ctx* ctx, const double* u, const double*
  * is (project it again if it has to be tangent with respect to the new metric).  Errors: Gaussian splitting (the
  * reference raises ValueError :293-300), M_0 not symmetric positive definite. */
 int chmc_set_metric(chmc_ctx* ctx, const double* M_0);
+/* One leaf of a batched dynamic-integration (no-U-turn) tree (the caller of integrator.step in the reference:
+ * mici.transitions.MultinomialDynamicIntegrationTransition, scripts/utils.py:292-301), fused into one pass over the state
+ * the last chmc_leapfrog_step produced.  The tree vectors stay with the caller as device buffers (plain pointers:
+ * sub_prop_q, sub_sum [B][Q]; ck_p, ck_sum [D][B][Q]).  For every chain with run[c] != 0:
+ *   sub_sum += mom;  sub_prop_q = pos if take[c];  ck_p[store_slot], ck_sum[store_slot] = mom, sub_sum (store_slot >= 0);
+ *   out[c][2k], out[c][2k + 1] = dh_dmom(ck_p[check_lo + k]) . span_k, dh_dmom(mom) . span_k for k < n_check, with
+ *   span_k = sub_sum - ck_sum[check_lo + k] + ck_p[check_lo + k]: the two sides of the no-U-turn criterion on the span
+ *   of leaves from checkpoint check_lo + k to this one (dh_dmom = metric.inv @ mom :1204-1208).
+ * out is [B][2 n_check] on the host (zeros for chains that did not run; may be NULL when n_check == 0); n_check <= 10.
+ * Sums are formed in a fixed order (no atomics).  run / take are host arrays (take is decided by the caller from
+ * chmc_hamiltonian of the same state: multinomial sampling of the sub-tree's proposal). */
+int chmc_tree_leaf(chmc_ctx* ctx, const int* run, const int* take, void* sub_prop_q_dev, void* sub_sum_dev,
+                   void* ck_p_dev, void* ck_sum_dev, int store_slot, int check_lo, int n_check, double* out);
 int chmc_set_momentum(chmc_ctx* ctx, const double* p);
 int chmc_get_state_device(chmc_ctx* ctx, void* q_dev, void* p_dev);  /* device-to-device copies */
 int chmc_set_momentum_device(chmc_ctx* ctx, const void* p_dev);

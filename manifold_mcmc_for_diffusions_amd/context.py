@@ -105,6 +105,17 @@ class ChmcContext:
         check(self.L.chmc_set_metric(self.h, ptr(m)), "chmc_set_metric")
         self.M_0 = m.copy()
 
+    def tree_leaf(self, run, take, sub_prop_q_ptr, sub_sum_ptr, ck_p_ptr, ck_sum_ptr, store_slot, check_lo, n_check):
+        """Fused bookkeeping of one leaf of the batched dynamic-integration trees (chmc_tree_leaf, include/chmc.h):
+        returns [B, 2 n_check] = the two no-U-turn criterion values per checked span."""
+        out = np.zeros((self.B, 2 * n_check))
+        r = np.ascontiguousarray(run, dtype=np.int32)
+        t = np.ascontiguousarray(take, dtype=np.int32)
+        check(self.L.chmc_tree_leaf(self.h, iptr(r), iptr(t), C.c_void_p(sub_prop_q_ptr), C.c_void_p(sub_sum_ptr),
+                                    C.c_void_p(ck_p_ptr), C.c_void_p(ck_sum_ptr), int(store_slot), int(check_lo),
+                                    int(n_check), ptr(out) if n_check else None), "chmc_tree_leaf")
+        return out
+
     def set_momentum(self, p):
         p = self._bq(p, "p")
         check(self.L.chmc_set_momentum(self.h, ptr(p)), "chmc_set_momentum")

@@ -184,6 +184,42 @@ static void launch_rows(F f, int ncol, int B, int cls = 0) {
     if (g_prof_pending.size() > 4096) prof_drain();
   }
 }
+// row-sum launch: as the row launch, with `nacc` per-item accumulators that are summed over the workgroup (wave
+// shuffles, then LDS) and written as one partial per (chain, workgroup): partial [B][gridDim.x][nacc].  No atomics:
+// the caller adds the partials of a chain in a fixed order, so the sums are reproducible.
+template <class F>
+__global__ void __launch_bounds__(256) k_rowsum(F f, int ncol, int nacc, double* partial) {
+  const int c = blockIdx.y;
+  if (!f.active(c)) return;  // uniform per workgroup
+  double acc[CHMC_ROWSUM_MAX];
+#pragma unroll
+  for (int a = 0; a < CHMC_ROWSUM_MAX; ++a) acc[a] = 0.0;
+  const int col = 2 * (blockIdx.x * 256 + threadIdx.x);
+  if (col < ncol) f(c, col, acc);
+  __shared__ double sm[4][CHMC_ROWSUM_MAX];
+#pragma unroll
+  for (int a = 0; a < CHMC_ROWSUM_MAX; ++a) {
+    if (a < nacc) {
+      double v = acc[a];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+      if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][a] = v;
+    }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nacc)
+    partial[((size_t)c * gridDim.x + blockIdx.x) * nacc + threadIdx.x] =
+        (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+}
+static int rowsum_groups(int ncol) { return ((ncol + 1) / 2 + 255) / 256; }
+template <class F>
+static void launch_rowsum(F f, int ncol, int B, int nacc, double* partial, int cls = 0) {
+  if (ncol <= 0 || B <= 0) return;
+  (void)cls;
+  hipLaunchKernelGGL(k_rowsum<F>, dim3((unsigned)rowsum_groups(ncol), (unsigned)B), dim3(256), 0, g_stream, f, ncol, nacc,
+                     partial);
+  note(hipGetLastError());
+}
 // column-max launch: grid (ceil(ncol / 256), B); f(c, col) returns a bit pattern that is max-reduced per chain
 template <class F>
 __global__ void __launch_bounds__(256) k_colmax(F f, int ncol) {

@@ -1900,6 +1900,93 @@ struct KNormPart {
     w.part[((size_t)c * npart + j) * 2 + 1] = pp;
   }
 };
+// One leaf of a dynamic (no-U-turn) trajectory tree, batched: everything the caller's tree bookkeeping needs from the
+// state the integrator has just produced, in ONE pass over its position and momentum (see chmc_tree_leaf in
+// include/chmc.h).  Row-sum launch: f(c, col, acc) handles components col, col + 1 of chain c and adds into the
+// per-item accumulators: acc[2k] += dh_dmom(ck_p[lo + k]) . span_k, acc[2k + 1] += dh_dmom(p) . span_k with span_k = sub_sum - ck_sum[lo + k] + ck_p[lo + k] (momentum sum of the leaves
+// from checkpoint lo + k to this one), dh_dmom = metric.inv @ mom (:1204-1208).
+#define CHMC_TREE_MAXCHK 10
+#define CHMC_ROWSUM_MAX (2 * CHMC_TREE_MAXCHK)
+struct KTreeLeaf {
+  Sys sy;
+  Slots sl;
+  const int* run;    // [B] chains that took this leaf
+  const int* take;   // [B] chains whose sub-tree proposal becomes this leaf
+  double* sub_prop_q;  // [B][Q]
+  double* sub_sum;     // [B][Q] momentum sum of the sub-tree's leaves so far
+  double* ck_p;        // [D][B][Q] momentum at the first leaf of a pending span
+  double* ck_sum;      // [D][B][Q] sub_sum at that leaf
+  int store, lo, nchk;  // store: checkpoint slot this leaf is recorded in (-1: none); checks against slots lo .. lo + nchk - 1
+  CHMC_HD bool active(int c) const { return run[c] != 0; }
+  CHMC_HD void operator()(int c, int col, double* acc) const {
+    const int s = sl.cur[c];
+    const size_t cq = (size_t)c * sy.Q, i = cq + col, BQ = (size_t)sy.B * sy.Q;
+    const bool two = col + 1 < sy.Q, wide = two && !(sy.Q & 1);
+    const double2_ q = ldv2(pick(sl.q, s) + i, wide, two), p = ldv2(pick(sl.p, s) + i, wide, two);
+    double2_ S = ldv2(sub_sum + i, wide, two);
+    S.x += p.x, S.y += p.y;
+    stv2(sub_sum + i, S, wide, two);
+    if (take[c]) stv2(sub_prop_q + i, q, wide, two);
+    if (store >= 0) {
+      stv2(ck_p + store * BQ + i, p, wide, two);
+      stv2(ck_sum + store * BQ + i, S, wide, two);
+    }
+    // velocity of this leaf (metric.inv @ p: only the u-part of the block metric differs from p)
+    double2_ vp = p;
+    const bool inu = sy.m0 && col < sy.U;
+    if (inu) {
+      vp.x = metric_inv_u(sy, pick(sl.p, s) + cq, col);
+      if (col + 1 < sy.U) vp.y = metric_inv_u(sy, pick(sl.p, s) + cq, col + 1);
+    }
+    CHMC_UNROLL
+    for (int k = 0; k < CHMC_TREE_MAXCHK; ++k) {
+      if (k < nchk) {
+        const double* cp = ck_p + (size_t)(lo + k) * BQ;
+        const double2_ a = ldv2(cp + i, wide, two), cs = ldv2(ck_sum + (size_t)(lo + k) * BQ + i, wide, two);
+        double2_ va = a;
+        if (inu) {
+          va.x = metric_inv_u(sy, cp + cq, col);
+          if (col + 1 < sy.U) va.y = metric_inv_u(sy, cp + cq, col + 1);
+        }
+        const double sx = S.x - cs.x + a.x, sy_ = two ? S.y - cs.y + a.y : 0.0;
+        acc[2 * k] += va.x * sx + (two ? va.y * sy_ : 0.0);
+        acc[2 * k + 1] += vp.x * sx + (two ? vp.y * sy_ : 0.0);
+      }
+    }
+  }
+};
+// second stage: the workgroup partials of a chain are added in a fixed order (reproducible sums);
+// out [B][2 nchk] = the two criterion values per checkpoint
+struct KTreeLeafFinish {
+  const int* run;
+  const double* partial;  // [B][nwg][nacc]
+  int nwg, nacc;
+  double* out;            // [B][nacc]
+  CHMC_HD void operator()(int c) const {
+    double* o = out + (size_t)c * nacc;
+    for (int a = 0; a < nacc; ++a) {
+      double t = 0.0;
+      if (run[c])
+        for (int g = 0; g < nwg; ++g) t += partial[((size_t)c * nwg + g) * nacc + a];
+      o[a] = t;
+    }
+  }
+};
+// q.q and p.p of the current state for the Hamiltonian (:1186-1202), row-sum launch: acc[0] += q.q, acc[1] += p.p
+struct KNormRow {
+  Sys sy;
+  Slots sl;
+  CHMC_HD bool active(int) const { return true; }
+  CHMC_HD void operator()(int c, int col, double* acc) const {
+    const int s = sl.cur[c];
+    const size_t i = (size_t)c * sy.Q + col;
+    const bool two = col + 1 < sy.Q, wide = two && !(sy.Q & 1);
+    const double2_ q = ldv2(pick(sl.q, s) + i, wide, two), p = ldv2(pick(sl.p, s) + i, wide, two);
+    acc[0] += q.x * q.x + (two ? q.y * q.y : 0.0);
+    acc[1] += p.x * p.x + (two ? p.y * p.y : 0.0);
+  }
+};
+
 // sample_momentum with the block metric: mom = metric.sqrt @ n (:1257), i.e. the u-part becomes chol(M_0) n_u
 struct KMetricSqrtU {
   Sys sy;

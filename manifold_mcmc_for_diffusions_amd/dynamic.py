@@ -127,13 +127,13 @@ class DynamicTransition:
             run = alive.copy()
             sub_logw = np.full(B, -np.inf)
             self.sub_sum.zero_()
+            self._sync()  # the library works on its own stream
             for k in range(1 << d):
                 if not run.any():
                     break
                 r = ctx.leapfrog_step(dt, active=run.astype(np.int32), **self.solver)
                 bad = run & (r["status"] != 0)
                 failed |= bad
-                self._fetch()
                 h = ctx.hamiltonian()[:, 0]
                 div = run & ~bad & ~((h - h0) <= self.max_delta_h)   # NaN counts as divergent
                 diverged |= div
@@ -146,25 +146,20 @@ class DynamicTransition:
                 new_logw = np.logaddexp(sub_logw, leaf_logw)
                 take = run & (un.get(un.LEAF, d, k) < np.exp(np.where(run, leaf_logw - np.where(run, new_logw, 0.0), -np.inf)))
                 sub_logw = np.where(run, new_logw, sub_logw)
-                tm, rm = self._mask(take), self._mask(run)
-                self.sub_prop_q.copy_(torch.where(tm[:, None], self.q, self.sub_prop_q))
-                self.sub_sum.add_(torch.where(rm[:, None], self.p, torch.zeros_like(self.p)))
-                # iterative no-U-turn checks over every sub-tree span that ends at this leaf
+                # one fused pass over the new state (chmc_tree_leaf): momentum sum, multinomial proposal, checkpoint of an
+                # even leaf, and for an odd leaf the iterative no-U-turn checks over every sub-tree span that ends here
                 lo, hi = _ckpt_range(k)
-                if k % 2 == 0:
-                    self.ck_p[hi].copy_(self.p)
-                    self.ck_sum[hi].copy_(self.sub_sum)
-                else:
-                    turning = torch.zeros(B, dtype=torch.bool, device=self.dev)
-                    for i in range(hi, lo - 1, -1):
-                        span = self.sub_sum - self.ck_sum[i] + self.ck_p[i]
-                        turning |= (self._dot(self.ck_p[i], span) < 0) | (self._dot(self.p, span) < 0)
-                    turn = run & turning.cpu().numpy()
+                even = k % 2 == 0
+                crit = ctx.tree_leaf(run, take, self.sub_prop_q.data_ptr(), self.sub_sum.data_ptr(), self.ck_p.data_ptr(),
+                                     self.ck_sum.data_ptr(), hi if even else -1, lo, 0 if even else hi - lo + 1)
+                if not even:
+                    turn = run & (crit < 0).any(1)
                     alive &= ~turn
                     run &= ~turn
             done = run  # chains whose sub-tree completed without terminating
             if not done.any():
                 continue
+            self._fetch()  # state after the sub-tree's last leaf: the tree's new edge
             depth_reached = np.where(done, d + 1, depth_reached)
             # biased progressive sampling between the old tree and the new sub-tree
             acc = done & (un.get(un.ACCEPT, d) < np.exp(np.minimum(0.0, sub_logw - logw)))

@@ -29,6 +29,21 @@ static void launch_rows(F f, int ncol, int B, int cls = 0) {
     for (int col = 0; col < ncol; col += 2) f(c, col);
   }
 }
+static int rowsum_groups(int ncol) { return ((ncol + 1) / 2 + 255) / 256; }
+template <class F>
+static void launch_rowsum(F f, int ncol, int B, int nacc, double* partial, int cls = 0) {
+  (void)cls;
+  const int ng = rowsum_groups(ncol);
+  for (int c = 0; c < B; ++c) {
+    if (!f.active(c)) continue;
+    for (int g = 0; g < ng; ++g) {
+      double acc[CHMC_ROWSUM_MAX];
+      for (int a = 0; a < CHMC_ROWSUM_MAX; ++a) acc[a] = 0.0;
+      for (int col = g * 512; col < ncol && col < (g + 1) * 512; col += 2) f(c, col, acc);
+      for (int a = 0; a < nacc; ++a) partial[((size_t)c * ng + g) * nacc + a] = acc[a];
+    }
+  }
+}
 template <class F>
 static void launch_colmax(F f, int ncol, int B, int cls = 0) {
   (void)cls;
