@@ -184,3 +184,52 @@ def check_block_metric_against_oracle(ctx, case, newton, dts, n_steps=2, tol=1e-
         osys.set_metric(None)
     check_ops_against_oracle(ctx, case)
     return worst
+
+
+def check_tree_leaf(ctx, case, device, with_metric):
+    """chmc_tree_leaf (fused per-leaf bookkeeping of the batched no-U-turn trees) against plain numpy on the same
+    buffers: momentum sum, proposal update, checkpoint store and the criterion values of the checked spans."""
+    import torch
+    rng, B, Q = case["rng"], ctx.B, ctx.Q
+    D = 4
+    M0 = random_metric(rng) if with_metric else None
+    ctx.set_metric(M0)
+    p = rng.standard_normal((B, Q))
+    ctx.set_state(case["q"], p, case["x_obs"], 0)
+    q0, p0, _, _ = ctx.get_state()
+    t = lambda a: torch.from_numpy(np.array(a, copy=True)).to(device)  # noqa: E731  (a copy: on the CPU the tensor would alias `a`)
+    sub_prop = rng.standard_normal((B, Q))
+    sub_sum = rng.standard_normal((B, Q))
+    ck_p, ck_sum = rng.standard_normal((D, B, Q)), rng.standard_normal((D, B, Q))
+    run = (np.arange(B) % 3 != 1).astype(np.int32)
+    take = (np.arange(B) % 2 == 0).astype(np.int32) & run
+    W = np.eye(Q)
+    if with_metric:
+        W[:4, :4] = np.linalg.inv(M0)
+
+    def expect(store, lo, n):
+        S = sub_sum + p0 * run[:, None]
+        prop = np.where((take == 1)[:, None], q0, sub_prop)
+        cp, cs = ck_p.copy(), ck_sum.copy()
+        if store >= 0:
+            cp[store] = np.where((run == 1)[:, None], p0, cp[store])
+            cs[store] = np.where((run == 1)[:, None], S, cs[store])
+        crit = np.zeros((B, 2 * n))
+        for k in range(n):
+            span = S - ck_sum[lo + k] + ck_p[lo + k]
+            crit[:, 2 * k] = ((ck_p[lo + k] @ W.T) * span).sum(1) * run
+            crit[:, 2 * k + 1] = ((p0 @ W.T) * span).sum(1) * run
+        return S, prop, cp, cs, crit
+
+    for store, lo, n in ((2, 0, 0), (-1, 1, 3), (-1, 0, 1)):
+        d_prop, d_sum, d_cp, d_cs = t(sub_prop), t(sub_sum), t(ck_p), t(ck_sum)
+        if device != "cpu":
+            torch.cuda.synchronize()
+        crit = ctx.tree_leaf(run, take, d_prop.data_ptr(), d_sum.data_ptr(), d_cp.data_ptr(), d_cs.data_ptr(), store, lo, n)
+        S, prop, cp, cs, ecrit = expect(store, lo, n)
+        np.testing.assert_allclose(d_sum.cpu().numpy(), S, rtol=0, atol=1e-14)
+        np.testing.assert_array_equal(d_prop.cpu().numpy(), prop)
+        np.testing.assert_array_equal(d_cp.cpu().numpy(), cp)
+        np.testing.assert_allclose(d_cs.cpu().numpy(), cs, rtol=0, atol=1e-14)
+        np.testing.assert_allclose(crit, ecrit, rtol=1e-11, atol=1e-9)
+    ctx.set_metric(None)

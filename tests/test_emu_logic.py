@@ -201,3 +201,13 @@ def test_block_metric_misuse(emu_lib):
     with pytest.raises(ValueError):
         ctx.set_metric(np.eye(3))
     ctx.close()
+
+
+@pytest.mark.parametrize("with_metric", [False, True])
+@pytest.mark.parametrize("model,T,S,R,noisy", [("fhn", 6, 4, 2, True), ("fhn", 7, 5, 3, False)])  # even and odd dim_q
+def test_tree_leaf(emu_lib, model, T, S, R, noisy, with_metric):
+    from helpers import check_tree_leaf
+    case = make_case(model, T, S, R, noisy, B=5, seed=51)
+    ctx = make_ctx(case)
+    check_tree_leaf(ctx, case, "cpu", with_metric)
+    ctx.close()

@@ -375,3 +375,14 @@ def test_block_metric(model, T, S, R, noisy, newton):
     ctx = make_ctx(case)
     check_block_metric_against_oracle(ctx, case, newton, np.array([0.05, -0.05, 0.08, 0.02]))
     ctx.close()
+
+
+@pytest.mark.parametrize("with_metric", [False, True])
+@pytest.mark.parametrize("model,T,S,R,noisy", [("fhn", 12, 16, 5, True), ("fhn", 7, 5, 3, False), ("sir", 6, 8, 2, True)])
+def test_tree_leaf(model, T, S, R, noisy, with_metric):
+    """chmc_tree_leaf (per-leaf bookkeeping of the batched no-U-turn trees) against numpy on the same device buffers."""
+    from helpers import check_tree_leaf
+    case = make_case(model, T, S, R, noisy, B=5, seed=51)
+    ctx = make_ctx(case)
+    check_tree_leaf(ctx, case, "cuda", with_metric)
+    ctx.close()
