@@ -142,6 +142,9 @@ int chmc_hamiltonian(chmc_ctx* ctx, double* h);        /* :1186-1202  [B][3] = {
  *   value [B] = 1/2 sum_t ((y_t - obs_func(x_t)) / sigma)^2 + T log sigma (+ 1/2 q.q unless use_gaussian_splitting),
  *   grad [B][QH] (may be NULL).  Needs a context with observation noise; does not touch the chain states. */
 int chmc_neg_log_dens_and_grad(chmc_ctx* ctx, const double* q, int use_gaussian_splitting, double* value, double* grad);
+/* The same with q_dev [B][U + V0 + T S V] and grad_dev (may be NULL) in device memory; `value` [B] on the host. */
+int chmc_neg_log_dens_and_grad_device(chmc_ctx* ctx, const void* q_dev, int use_gaussian_splitting, double* value,
+                                      void* grad_dev);
 
 /* Projection solvers (newton != 0: newton_projection :1065-1135 with its host wrapper :1405-1476;
  * newton == 0: quasi_newton_projection :999-1063 / :1323-1402).  Projects the points q [B][Q] onto the manifold

@@ -241,6 +241,14 @@ class ChmcContext:
               "chmc_neg_log_dens_and_grad")
         return val, g
 
+    def neg_log_dens_and_grad_device(self, q_dev_ptr, grad_dev_ptr=None, use_gaussian_splitting=False):
+        """The same on device buffers (q [B, U + V0 + T S V] and, optionally, the gradient): returns the values [B]."""
+        val = np.empty(self.B)
+        check(self.L.chmc_neg_log_dens_and_grad_device(self.h, C.c_void_p(q_dev_ptr), int(bool(use_gaussian_splitting)),
+                                                       ptr(val), C.c_void_p(grad_dev_ptr or 0)),
+              "chmc_neg_log_dens_and_grad_device")
+        return val
+
     def project(self, q, dt, newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10, max_iters=50):
         q = self._bq(q, "q")
         dt = as_c(np.broadcast_to(np.asarray(dt, dtype=np.float64), (self.B,)))

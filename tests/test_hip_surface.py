@@ -85,3 +85,45 @@ def test_unconstrained_hmc_comparator_surface():
     assert vb.shape == (2,) and gb.shape == (2, q.size) and abs(vb[0] - v) <= 1e-12 * abs(v)
     with pytest.raises(mm.HamiltonianDivergenceError):
         nld(np.full_like(q, 1e200))
+
+
+def test_hmc_target_on_device_buffers_and_comparator_sampler():
+    """chmc_neg_log_dens_and_grad_device equals the host-pointer entry point; the batched unconstrained HMC sampler on
+    that target (hmc.py: the reference's comparator, scripts/utils.py:203-250) and the constrained sampler draw from the
+    same posterior of the global parameters (the paper's premise), compared through their chain means."""
+    import torch
+    from manifold_mcmc_for_diffusions_amd.context import ChmcContext
+    from manifold_mcmc_for_diffusions_amd.init import fhn_initial_states
+    from manifold_mcmc_for_diffusions_amd.sampling import sample_static_chmc
+    from manifold_mcmc_for_diffusions_amd.hmc import sample_hmc
+    T, S, R, sigma, B = 8, 8, 4, 0.1, 64
+    y = em.simulate_fhn_observations(T, 0.2, 50, seed=5, sigma=sigma)
+    ctx = ChmcContext("fhn", 0.2, S, R, y[:, 0], sigma=sigma, num_chains=B)
+    q, xo, _ = fhn_initial_states(em.fhn, 0.2, S, y, B, True, seed=7)
+    QH = ctx.U + ctx.NV
+    qh = np.ascontiguousarray(q[:, :QH])
+    v_host, g_host = ctx.neg_log_dens_and_grad(qh)
+    qd = torch.from_numpy(qh).cuda()
+    gd = torch.empty_like(qd)
+    torch.cuda.synchronize()
+    v_dev = ctx.neg_log_dens_and_grad_device(qd.data_ptr(), gd.data_ptr())
+    np.testing.assert_array_equal(v_dev, v_host)
+    np.testing.assert_array_equal(gd.cpu().numpy(), g_host)
+    np.testing.assert_array_equal(ctx.neg_log_dens_and_grad_device(qd.data_ptr()), v_host)  # value only
+    # comparator sampler, three metric options of the reference's script
+    res = {}
+    for mt in ("identity", "diagonal", "block"):
+        res[mt] = sample_hmc(ctx, qh, 500, 12, 0.02, seed=11, n_adapt=200, metric_type=mt, jitter_length=True)
+        assert np.isfinite(res[mt]["heads"]).all() and 0.5 < res[mt]["accept_stat"][200:].mean() < 0.98
+    assert res["block"]["metric"].kind == "block" and res["diagonal"]["metric"].kind == "diagonal"
+    ctx.set_state(q, None, xo, 0)
+    ch = sample_static_chmc(ctx, 500, 8, 0.1, seed=3, n_adapt=200, jitter_length=True)
+    zc = em.fhn.generate_z(ch["heads"][200:, :, :4])  # [draw, chain, 4]
+    for mt in ("identity", "block"):
+        zh = em.fhn.generate_z(res[mt]["heads"][200:, :, :4])
+        for k in range(4):
+            a, b = np.log(zc[..., k]) if k < 3 else zc[..., k], np.log(zh[..., k]) if k < 3 else zh[..., k]
+            ma, mb = a.mean(0), b.mean(0)  # chain means
+            se = np.sqrt(ma.var(ddof=1) / B + mb.var(ddof=1) / B)
+            assert abs(ma.mean() - mb.mean()) < 4.5 * se, (mt, k, ma.mean(), mb.mean(), se)
+    ctx.close()
