@@ -1719,28 +1719,7 @@ struct KFlow {
 // The accumulated multiplier term mu = sum of the position updates is the distance the retraction moved the
 // iterate, mu = h2_flow(q_prev, p) - q_new, so it is re-formed here from the two positions and the momentum instead
 // of being carried (read + written) through every Newton iteration.
-struct KMomFix {
-  Sys sy;
-  Slots sl;
-  Work w;
-  int which;
-  CHMC_HD void operator()(int tid) const {
-    const int c = tid / sy.Q;
-    if (!w.ok[c]) return;
-    const int s = sl.cur[c] ^ which;  // the new point; the flow started from slot s ^ 1 with this slot's momentum
-    const double qp = pick(sl.q, s ^ 1)[tid], qn = pick(sl.q, s)[tid], pn = pick(sl.p, s)[tid];
-    double sc, flow;
-    if (sy.gaussian) {  // q cos + p0 sin with p0 recovered from the rotated momentum: (q + sin p_n) / cos
-      sc = w.cdt[c] / w.sdt[c];
-      flow = (qp + w.sdt[c] * pn) / w.cdt[c];
-    } else {
-      sc = 1.0 / w.dt[c];
-      flow = qp + w.dt[c] * pn;
-    }
-    pick(sl.p, s)[tid] = pn - sc * (flow - qn);
-  }
-};
-// KMomFix and KInitPg of the new point in one pass (both only need the positions, the momentum and the gradient)
+// ... fused with KInitPg of the new point in one pass (both only need the positions, the momentum and the gradient)
 struct KMomFixInitPg {
   Sys sy;
   Slots sl;
@@ -1879,25 +1858,6 @@ struct KBegin {
       w.cdt[c] = cos(dt[c]);
     }
     w.rev[c] = 0ULL;
-  }
-};
-// partial sums of q.q and p.p for the Hamiltonian (:1186-1202): NPART partials per chain
-struct KNormPart {
-  Sys sy;
-  Slots sl;
-  Work w;
-  int npart;
-  CHMC_HD void operator()(int tid) const {
-    const int c = tid / npart, j = tid - c * npart;
-    const int s = sl.cur[c];
-    const int chunk = (sy.Q + npart - 1) / npart;
-    const int lo = j * chunk, hi = lo + chunk < sy.Q ? lo + chunk : sy.Q;
-    double qq = 0.0, pp = 0.0;
-    const double* q = pick(sl.q, s) + (size_t)c * sy.Q;
-    const double* p = pick(sl.p, s) + (size_t)c * sy.Q;
-    for (int i = lo; i < hi; ++i) qq += q[i] * q[i], pp += p[i] * p[i];
-    w.part[((size_t)c * npart + j) * 2] = qq;
-    w.part[((size_t)c * npart + j) * 2 + 1] = pp;
   }
 };
 // One leaf of a dynamic (no-U-turn) trajectory tree, batched: everything the caller's tree bookkeeping needs from the
