@@ -75,7 +75,14 @@ def cpu_baseline(wl, q, p, xo, part, dt, n_steps, solver):
     with ThreadPoolExecutor(cores) as ex:
         done = sum(ex.map(run, chains))
     el = time.perf_counter() - t0
-    return {"value": done / el, "unit": "steps/s", "cores": cores, "kind": "port",
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    return {"value": done / el, "unit": "steps/s", "cores": cores, "kind": "port", "cpu_model": model,
+            "per_core": done / el / cores,
             "sample": f"{cores} chains x {n_steps} leapfrog steps from post-burn-in states, C oracle "
                       f"(oracle/c/chmc_oracle.c, gcc -O2), one chain per host thread, {el:.1f} s"}
 
