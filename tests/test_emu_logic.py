@@ -83,6 +83,12 @@ def test_api_misuse_is_reported(emu_lib):
         ChmcContext("fhn", 0.2, 4, 2, np.zeros(6), sigma=0.0)
     with pytest.raises(RuntimeError, match="not supported"):
         ChmcContext("fhn", 0.2, 4, None, np.zeros(20), sigma=0.1)  # unpartitioned FHN: 20 rows in one block
+    with pytest.raises(RuntimeError, match="at least 2"):  # second partition would open with 1 // 2 = 0 observations
+        ChmcContext("fhn", 0.2, 4, 1, np.zeros(6), sigma=0.1)
+    from oracle import c_oracle
+    with pytest.raises(ValueError):
+        c_oracle.OracleSystem("fhn", 0.2, 4, 1, np.zeros(6), sigma=0.1)
+    ChmcContext("fhn", 0.2, 4, 1, np.zeros(1), sigma=0.1).close()  # a single observation is a single sub-sequence
     case = make_case("fhn", 6, 4, 2, True, B=2, seed=1)
     ctx = make_ctx(case)
     with pytest.raises(ValueError):
