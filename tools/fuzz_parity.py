@@ -4,7 +4,8 @@ Configurations whose random state is numerically degenerate in the ORACLE (non-f
 beyond 1e6) are skipped; the per-op tolerance is 1e-8 instead of the tests' 1e-10 because random noiseless configurations
 are badly conditioned (cond(C) ~ 1e6), and a step whose Newton iteration count differs by one at the edge of the
 convergence tolerance is reported as borderline, not as a failure.
-usage: python tools/fuzz_parity.py [n_trials] [seed] [emu]      (emu: the test-only host emulation build)"""
+usage: python tools/fuzz_parity.py [n_trials] [seed] [emu|hip] [small|mid]    (emu: the test-only host emulation build;
+mid: 40-400 steps per observation, i.e. many 64-step tiles per block in the wave kernels)"""
 import ctypes
 import os
 import sys
@@ -21,12 +22,13 @@ if len(sys.argv) > 3 and sys.argv[3] == "emu":
     _lib._LIB = _lib._bind(ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libchmc_emu.so")))
 from helpers import make_case, make_ctx, check_ops_against_oracle, check_steps_against_oracle, random_metric  # noqa: E402
 
+mid = len(sys.argv) > 4 and sys.argv[4] == "mid"
 rng = np.random.default_rng(seed)
 fails, ran, skipped, borderline = [], 0, 0, 0
 for trial in range(n_trials):
     model = str(rng.choice(["fhn", "sir", "fhn_nb"]))
-    T = int(rng.integers(2, 15))
-    S = int(rng.choice([3, 5, 8, 8, 16, 24]))
+    T = int(rng.integers(2, 9 if mid else 15))
+    S = int(rng.choice([40, 64, 200, 400] if mid else [3, 5, 8, 8, 16, 24]))
     R = [None, 2, 3, 4, 5, 7][int(rng.integers(0, 6))]
     noisy = bool(rng.integers(0, 2)) or model == "sir"
     gaussian = bool(rng.integers(0, 2)) and model != "sir"
