@@ -109,9 +109,12 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   const int ntile = (S + 63) >> 6;
   const int ntot = bd.nobs * ntile;
   struct Raw {
-    double x[X], v[V], jp[RM * V];
+    double x[X], v[V];
     bool valid;
     int s;
+  };
+  struct Rows {  // stored rows of slot `which` at the tile's steps (MODE 1 with Gram): requested ONE tile ahead
+    double jp[(MODE == 1 && GRAM) ? RM * V : 1];
   };
   struct Scan {
     double Bm[X * V], Zf[X * Z], E[X * X], I0[X * X];
@@ -126,21 +129,24 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
       for (int a = 0; a < X; ++a) r.x[a] = ld_stream(traj + (size_t)r.s * X + a);
 #pragma unroll
       for (int a = 0; a < V; ++a) r.v[a] = vbase[(size_t)r.s * V + a];
-      if (MODE == 1 && GRAM) {
-        const size_t col = colb + (size_t)r.s * V;
-#pragma unroll URM
-        for (int i = 0; i < RM; ++i)  // (skipping the structurally zero rows here breaks the load pipelining: 2x slower)
-#pragma unroll
-          for (int d = 0; d < V; ++d) r.jp[i * V + d] = ld_stream(Jr + (size_t)i * NV + col + d);
-      }
     } else {
 #pragma unroll
       for (int a = 0; a < X; ++a) r.x[a] = 0.0;
 #pragma unroll
       for (int a = 0; a < V; ++a) r.v[a] = 0.0;
-      if (MODE == 1 && GRAM) {
+    }
+  };
+  auto fetch_rows = [&](const Raw& r, Rows& o) {
+    if (MODE == 1 && GRAM) {
+      if (r.valid) {
+        const size_t col = colb + (size_t)r.s * V;
 #pragma unroll URM
-        for (int i = 0; i < RM * V; ++i) r.jp[i] = 0.0;
+        for (int i = 0; i < RM; ++i)  // (skipping the structurally zero rows here breaks the load pipelining: 2x slower)
+#pragma unroll
+          for (int d = 0; d < V; ++d) o.jp[i * V + d] = ld_stream(Jr + (size_t)i * NV + col + d);
+      } else {
+#pragma unroll URM
+        for (int i = 0; i < RM * V; ++i) o.jp[i] = 0.0;
       }
     }
   };
@@ -178,7 +184,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
       o.I0[i] = bcast0(Inc[i]);  // lane 0's inclusive product carries the rows across the tile
     }
   };
-  auto stage2 = [&](const Scan& sc, const Raw& r) {
+  auto stage2 = [&](const Scan& sc, const Raw& r, const Rows& rw) {
     double Ls[RM * X], jr[RM * V];
 #pragma unroll URM
     for (int i = 0; i < RM; ++i) {
@@ -237,7 +243,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
         for (int jj = 0; jj < RM; ++jj) {
           double tt2 = Dacc[i * RM + jj];
 #pragma unroll
-          for (int d = 0; d < V; ++d) tt2 += jr[i * V + d] * r.jp[jj * V + d];
+          for (int d = 0; d < V; ++d) tt2 += jr[i * V + d] * rw.jp[jj * V + d];
           Dacc[i * RM + jj] = tt2;
         }
     }
@@ -257,13 +263,16 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
     }
   };
   Raw r0, r1, r2;
+  Rows w0, w1;
   Scan sc0, sc1;
   fetch(ntot - 1, r0);
+  fetch_rows(r0, w0);
   fetch(ntot - 2, r1);
   stage1(r0, sc0);
   for (int tt = ntot - 1; tt >= 0; --tt) {
     const int j = tt / ntile, t = tt - j * ntile;
     fetch(tt - 2, r2);
+    fetch_rows(r1, w1);
     if (t == ntile - 1) {
       // rows that start at the end of observation interval j
       if (j < bd.ny) {
@@ -284,9 +293,10 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
       }
     }
     stage1(r1, sc1);  // tile tt - 1 (identity when there is none)
-    stage2(sc0, r0);  // tile tt
+    stage2(sc0, r0, w0);  // tile tt
     r0 = r1;
     r1 = r2;
+    w0 = w1;
     sc0 = sc1;
   }
   // x_0 = generate_x_0(z, v_0): the v_0 columns and the z-dependence of the first block (lane 0's share)

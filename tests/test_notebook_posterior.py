@@ -28,7 +28,7 @@ def test_posterior_matches_the_notebook_table(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import fhn_notebook_posterior as nb
     rows, res, n_moving = nb.run(64, 700, 200, 24, out_dir=str(tmp_path / "run"), verbose=False)
-    assert n_moving >= 58                               # at most a few stuck starts
+    assert n_moving >= 56                               # at most a few stuck starts
     assert 0.6 < res["accept_stat"][200:].mean() < 0.95
     for r in rows:
         assert abs(r["z"]) < 4.0, r                     # means agree within Monte-Carlo error
