@@ -229,7 +229,12 @@ def main():
                          "algorithmic_bytes_per_launch": per_chain * chains_per_launch,
                          "algorithmic_bytes_per_chain": per_chain, "chains_per_launch": chains_per_launch,
                          "avg_launch_ms": avg_ms,
-                         "launches_timed": int(nl[dom]), "timed_every": a.profile_stride},
+                         "launches_timed": int(nl[dom]), "timed_every": a.profile_stride,
+                         "hbm_traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                         "note": "achieved = operator-level algorithmic bytes (SURVEY.md 8d) / launch time; the kernel "
+                                 "never materialises the iterate's Jacobian, so this can exceed the HBM peak; "
+                                 "`traffic` is the measured HBM bytes per launch (PMC), `hbm_traffic_frac` its rate "
+                                 "against the peak (the kernel is bound by fp64 VALU issue, DESIGN.md section 4)"},
         }
         if world == 1 and not a.no_cpu_baseline:
             q, p, xo, part = ctx.get_state()
