@@ -75,6 +75,14 @@ def cpu_baseline(wl, q, p, xo, part, dt, n_steps, solver):
     with ThreadPoolExecutor(cores) as ex:
         done = sum(ex.map(run, chains))
     el = time.perf_counter() - t0
+    # one chain alone on one core (the reference takes its op timings pinned to a single core,
+    # run_fhn_model_noiseless_obs_experiments.sh:115): a quarter of the steps, continuing from chain 0's state
+    n1 = max(n_steps // 4, 8)
+    t1 = time.perf_counter()
+    for _ in range(n1):
+        chains[0].step(dt, newton=solver["newton"], ctol=solver["constraint_tol"], ptol=solver["position_tol"],
+                       dtol=solver["divergence_tol"], max_iters=solver["max_iters"], rev_tol=solver["reverse_check_tol"])
+    single = n1 / (time.perf_counter() - t1)
     model = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
@@ -82,7 +90,7 @@ def cpu_baseline(wl, q, p, xo, part, dt, n_steps, solver):
     except OSError:
         pass
     return {"value": done / el, "unit": "steps/s", "cores": cores, "kind": "port", "cpu_model": model,
-            "per_core": done / el / cores,
+            "per_core": done / el / cores, "single_core_alone": single,
             "sample": f"{cores} chains x {n_steps} leapfrog steps from post-burn-in states, C oracle "
                       f"(oracle/c/chmc_oracle.c, gcc -O2), one chain per host thread, {el:.1f} s"}
 
