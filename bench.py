@@ -5,11 +5,15 @@ One "step" = one batched ConstrainedLeapfrogIntegrator.step over the chains resi
 BASELINE.json configs[1]); weak scaling over GPUs (chains shard, no data-path collective, one RCCL gather of the
 traced samples).  Prints ONE JSON line on rank 0.  See DESIGN.md "Measurement".
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a torchrun environment: spawns the N ranks itself)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...
+
+Other BASELINE.json configurations (parity-test cases; their lines are kept under profiles/):
+  --config fhn_noiseless | sir      --solver quasi-newton      --splitting gaussian
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -21,7 +25,17 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 METRIC = "constrained-leapfrog steps/sec (all chains), FHN noisy-obs 400 sub-steps"
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+FP64_VALU_PEAK_TFLOPS = 78.6   # fp64 vector peak: 256 CU x 4 SIMD x 16 FMA lanes/clk x 2 flop x 2.4 GHz
+
+# Algorithmic flops of the SDE recursion per time step (+-30 % estimates): forward step,
+# Jacobian sweep = shared part + per live adjoint row.  (SIR: scaled from its X = V = 3 one-step map.)
+FLOPS = {"fhn": dict(fwd=32.0, jac_shared=15.0, jac_row=28.0), "sir": dict(fwd=60.0, jac_shared=40.0, jac_row=52.0)}
+# what binds each kernel class on gfx950: "hbm" classes stream stored rows / state vectors,
+# "fp64_valu" classes regenerate the Jacobian in registers and are bound by fp64 vector issue
+BOUND = {"newton_blk": "fp64_valu", "state_blk": "fp64_valu", "grad_log_det_blk": "fp64_valu", "constr": "fp64_valu",
+         "update": "hbm", "jacob_vec": "hbm", "elementwise": "hbm", "solve_chain": "latency", "sym_blk": "latency",
+         "other": "latency"}
 
 
 def parse():
@@ -29,26 +43,47 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--config", default="fhn_noisy", choices=["fhn_noisy", "fhn_noiseless", "sir"],
+                    help="fhn_noisy = BASELINE.json configs[1] (the metric); fhn_noiseless = configs[2]; sir = configs[3]")
+    ap.add_argument("--solver", default="newton", choices=["newton", "quasi-newton"])
+    ap.add_argument("--splitting", default="standard", choices=["standard", "gaussian"])
     ap.add_argument("--chains-per-gpu", type=int, default=256)
-    ap.add_argument("--num-steps-per-obs", type=int, default=400)
-    ap.add_argument("--step-size", type=float, default=0.1)
+    ap.add_argument("--num-steps-per-obs", type=int, default=None, help="default 400 (FHN) / 200 (SIR)")
+    ap.add_argument("--num-obs", type=int, default=100, help="FHN only (rehearsals)")
+    ap.add_argument("--step-size", type=float, default=None)
     ap.add_argument("--traj-len", type=int, default=16, help="leapfrog steps between momentum refreshes")
     ap.add_argument("--burn-iters", type=int, default=5)
     ap.add_argument("--burn-steps", type=int, default=16)
-    ap.add_argument("--burn-step-size", type=float, default=0.1)
+    ap.add_argument("--burn-step-size", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="record no HIP events in the timed region")
     ap.add_argument("--profile-stride", type=int, default=1,
                     help="timed region: HIP events around every n-th launch of the dominant kernel (an event pair "
                          "costs the stream ~30 us, timing every launch slows the region by ~5 %%)")
-    ap.add_argument("--cpu-steps", type=int, default=250)
+    ap.add_argument("--cpu-steps", type=int, default=None)
+    ap.add_argument("--data-steps-per-obs", type=int, default=10000, help="fine grid of the simulated FHN data")
     return ap.parse_args()
 
 
-def cpu_baseline(wl, q, p, xo, part, dt, n_steps, solver):
+def spawn_ranks(a):
+    """`--gpus N` outside a torchrun environment: start the N ranks as child processes (one per GPU, RCCL) BEFORE this
+    process touches torch.cuda or the HIP library, relay their output and exit with their code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
+
+
+def cpu_baseline(wl, model, q, p, xo, part, dt, n_steps, solver, gaussian):
     """The C oracle (kind "port": the reference itself cannot run here) on the host cores, one chain per thread
     (ctypes releases the GIL), on a bounded sample of the same workload: `cores` chains x n_steps leapfrog steps from
-    the chains' post-burn-in states."""
+    the chains' post-burn-in states.  `value` is the -O3 -march=native build compiled on this machine; the portable -O2
+    build the parity tests use is timed beside it on a quarter of the sample."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import c_oracle
     try:
@@ -56,71 +91,158 @@ def cpu_baseline(wl, q, p, xo, part, dt, n_steps, solver):
     except AttributeError:
         avail = os.cpu_count() or 1
     cores = max(1, min(len(q), avail, 16))  # a one-GPU box has a 16-core CPU share
-    osys = c_oracle.OracleSystem("fhn", wl.obs_interval, wl.S, wl.R, wl.y[:, 0], sigma=wl.sigma)
-    chains = []
-    for c in range(cores):
-        ch = c_oracle.OracleChain(osys)
-        ch.set(q[c], p[c], xo[c], part)  # state caches evaluated here, outside the timed region
-        chains.append(ch)
+    kw = dict(newton=solver["newton"], ctol=solver["constraint_tol"], ptol=solver["position_tol"],
+              dtol=solver["divergence_tol"], max_iters=solver["max_iters"], rev_tol=solver["reverse_check_tol"])
 
-    def run(ch):
-        n = 0
-        for _ in range(n_steps):
-            ch.step(dt, newton=solver["newton"], ctol=solver["constraint_tol"], ptol=solver["position_tol"],
-                    dtol=solver["divergence_tol"], max_iters=solver["max_iters"], rev_tol=solver["reverse_check_tol"])
-            n += 1
-        return n
+    def timed(kind, n):
+        c_oracle.select_build(kind)
+        osys = c_oracle.OracleSystem(model, wl.obs_interval, wl.S, wl.R, wl.y[:, 0], sigma=wl.sigma,
+                                     use_gaussian_splitting=gaussian)
+        chains = []
+        for c in range(cores):
+            ch = c_oracle.OracleChain(osys)
+            ch.set(q[c], p[c], xo[c], part)  # state caches evaluated here, outside the timed region
+            chains.append(ch)
 
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        done = sum(ex.map(run, chains))
-    el = time.perf_counter() - t0
-    # one chain alone on one core (the reference takes its op timings pinned to a single core,
-    # run_fhn_model_noiseless_obs_experiments.sh:115): a quarter of the steps, continuing from chain 0's state
-    n1 = max(n_steps // 4, 8)
-    t1 = time.perf_counter()
-    for _ in range(n1):
-        chains[0].step(dt, newton=solver["newton"], ctol=solver["constraint_tol"], ptol=solver["position_tol"],
-                       dtol=solver["divergence_tol"], max_iters=solver["max_iters"], rev_tol=solver["reverse_check_tol"])
-    single = n1 / (time.perf_counter() - t1)
-    model = "unknown"
+        def run(ch):
+            for _ in range(n):
+                ch.step(dt, **kw)
+            return n
+
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            done = sum(ex.map(run, chains))
+        el = time.perf_counter() - t0
+        # one chain alone on one core (the reference takes its op timings pinned to a single core,
+        # run_fhn_model_noiseless_obs_experiments.sh:115): a quarter of the steps, continuing from chain 0's state
+        n1 = max(n // 4, 4)
+        t1 = time.perf_counter()
+        for _ in range(n1):
+            chains[0].step(dt, **kw)
+        return done / el, n1 / (time.perf_counter() - t1), el
+
+    try:
+        v_nat, single_nat, el = timed("native", n_steps)
+        flags = c_oracle.CFLAGS
+        v_port, single_port, _ = timed("portable", max(n_steps // 4, 4))
+    finally:
+        c_oracle.select_build("portable")
+    model_name = "unknown"
     try:
         with open("/proc/cpuinfo") as f:
-            model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+            model_name = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
     except OSError:
         pass
-    return {"value": done / el, "unit": "steps/s", "cores": cores, "kind": "port", "cpu_model": model,
-            "per_core": done / el / cores, "single_core_alone": single,
+    return {"value": v_nat, "unit": "steps/s", "cores": cores, "kind": "port", "cpu_model": model_name,
+            "per_core": v_nat / cores, "single_core_alone": single_nat, "compiler_flags": "gcc " + flags,
+            "portable_O2_build": {"value": v_port, "single_core_alone": single_port,
+                                  "compiler_flags": "gcc " + c_oracle.PORTABLE_CFLAGS},
             "sample": f"{cores} chains x {n_steps} leapfrog steps from post-burn-in states, C oracle "
-                      f"(oracle/c/chmc_oracle.c, gcc -O2), one chain per host thread, {el:.1f} s"}
+                      f"(oracle/c/chmc_oracle.c, gcc {flags}), one chain per host thread, {el:.1f} s"}
+
+
+def _finite(o):
+    """NaN / inf are not JSON: unmeasured figures are printed as null."""
+    if isinstance(o, dict):
+        return {k: _finite(v) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_finite(v) for v in o]
+    if isinstance(o, float) and not np.isfinite(o):
+        return None
+    return o
+
+
+def lib_sha256():
+    from manifold_mcmc_for_diffusions_amd import _lib
+    h = hashlib.sha256()
+    with open(_lib._SO, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()
+
+
+def class_model(ctx, wl, model, newton):
+    """Per kernel class: algorithmic bytes and flops per chain of ONE launch (SURVEY.md 8d operator decomposition)."""
+    nnz, Q = wl.nnz(), ctx.Q
+    f = FLOPS[model]
+    blocks = ctx.blocks[ctx.partition]
+    n_s = ctx.T * ctx.S
+    live = 0.0  # sum over time steps of the live adjoint rows (observation row i is zero after its own interval)
+    gram_ns = gram_sym = 0.0
+    for b in blocks:
+        x_rows = b["nrows"] - b["ny"]
+        for m in range(b["nobs"]):
+            live += ctx.S * (max(b["ny"] - m, 0) + x_rows)
+        gram_ns += 2.0 * b["nrows"] ** 2 * b["ncols"]
+        gram_sym += 1.0 * b["nrows"] * (b["nrows"] + 1) * b["ncols"]
+    jac = f["jac_shared"] * n_s + f["jac_row"] * live
+    return {
+        # newton_blk = constr (Q) + jacob_constr_blocks (Q + nnz written) + lu_jacob_product_blocks (2 nnz)
+        "newton_blk": dict(bytes=8.0 * (3 * nnz + 2 * Q), flops=jac + gram_ns),
+        # state_blk  = constr (Q) + jacob (Q + nnz) + chol_gram_blocks (nnz)
+        "state_blk": dict(bytes=8.0 * (2 * nnz + 2 * Q), flops=jac + gram_sym),
+        "grad_log_det_blk": dict(bytes=8.0 * (4 * nnz + 2 * Q), flops=2.0 * (jac + gram_ns)),  # two sweeps per evaluation
+        "update": dict(bytes=8.0 * (nnz + 6 * Q), flops=2.0 * nnz),
+        "jacob_vec": dict(bytes=8.0 * (nnz + Q), flops=2.0 * nnz),
+        "constr": dict(bytes=8.0 * 2 * Q, flops=f["fwd"] * n_s),
+        "elementwise": dict(bytes=8.0 * 3 * Q, flops=2.0 * Q),
+    }
 
 
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        spawn_ranks(a)
     from manifold_mcmc_for_diffusions_amd import distributed as D
-    rank, local_rank, world = D.init_process_group()
-    if world != a.gpus and world > 1:
+    emu = os.environ.get("CHMC_BENCH_EMU_LIB")  # TEST-ONLY: CPU rehearsal of the launcher / multi-rank path (tests/)
+    rank, local_rank, world = D.init_process_group("gloo" if emu else None)
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} does not match WORLD_SIZE {world}")
     import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
-    devno = int(os.environ.get("CHMC_BENCH_DEVICE", local_rank))  # override only for single-GPU rehearsals
-    torch.cuda.set_device(devno)
-    dev = torch.device("cuda", devno)
     from manifold_mcmc_for_diffusions_amd import _lib
-    from manifold_mcmc_for_diffusions_amd.workload import FhnWorkload
+    if emu:
+        _lib._LIB = _lib._bind(C.CDLL(emu))
+        dev, devno = torch.device("cpu"), 0
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+        devno = int(os.environ.get("CHMC_BENCH_DEVICE", local_rank))  # override only for single-GPU rehearsals
+        torch.cuda.set_device(devno)
+        dev = torch.device("cuda", devno)
+    sync = (lambda: None) if emu else torch.cuda.synchronize
+    from manifold_mcmc_for_diffusions_amd.workload import FhnWorkload, SirWorkload
     L = _lib.lib()
     B = a.chains_per_gpu
-    wl = FhnWorkload(B, num_steps_per_obs=a.num_steps_per_obs, device=devno, chain_offset=rank * B,
-                     total_chains=world * B)
+    gaussian = a.splitting == "gaussian"
+    model = "sir" if a.config == "sir" else "fhn"
+    if a.config == "sir":
+        S = a.num_steps_per_obs or 200
+        wl = SirWorkload(B, num_steps_per_obs=S, device=devno, chain_offset=rank * B, total_chains=world * B,
+                         use_gaussian_splitting=gaussian)
+        step_size = a.step_size if a.step_size is not None else 0.25
+        workload = (f"SIR boarding-school data, T=14 obs, S={S} steps/obs, one sub-sequence of R=14 (dense 14x14 Gram), "
+                    f"sigma_y=1, {B} chains per GPU (BASELINE.json configs[3])")
+    else:
+        S = a.num_steps_per_obs or 400
+        noisy = a.config == "fhn_noisy"
+        wl = FhnWorkload(B, num_steps_per_obs=S, num_obs=a.num_obs, sigma=0.1 if noisy else None, device=devno,
+                         chain_offset=rank * B, total_chains=world * B, use_gaussian_splitting=gaussian,
+                         num_steps_per_obs_data=a.data_steps_per_obs)
+        step_size = a.step_size if a.step_size is not None else 0.1
+        workload = (f"FHN {'noisy' if noisy else 'noiseless'}-obs, T={a.num_obs} obs, S={S} steps/obs, R=5 obs/subseq, "
+                    f"{'sigma_y=0.1, ' if noisy else ''}{B} chains per GPU "
+                    f"(BASELINE.json configs[{1 if noisy else 2}])")
+    wl.solver["newton"] = a.solver == "newton"
+    workload += f", {'Newton' if wl.solver['newton'] else 'quasi-Newton'} solver, {a.splitting} splitting"
+    burn_step = a.burn_step_size if a.burn_step_size is not None else step_size
     ctx = wl.ctx
 
-    # ---- untimed burn-in: the linear-interpolation initial states are far from the typical set
+    # ---- untimed burn-in: the initial states are far from the typical set
     for _ in range(a.burn_iters):
         wl.refresh_momentum()
         act = np.ones(B, dtype=np.int32)
         for _ in range(a.burn_steps):
-            r = wl.step(a.burn_step_size, active=act)
+            r = wl.step(burn_step, active=act)
             act &= (r["status"] == 0).astype(np.int32)
         ctx.switch_partition()
 
@@ -131,7 +253,7 @@ def main():
                 if k:
                     ctx.switch_partition()
                 wl.refresh_momentum()  # device-side Philox stream + projection
-            r = wl.step(a.step_size)
+            r = wl.step(step_size)
             k += 1
             if stats is not None:
                 stats.append(r)
@@ -147,7 +269,7 @@ def main():
     L.chmc_profile_get(ms_w.ctypes.data_as(_lib.dp), nl_w.ctypes.data_as(C.POINTER(C.c_longlong)))
     dom = int(np.argmax(ms_w)) if a.warmup > 0 else 1
     D.barrier()
-    torch.cuda.synchronize()
+    sync()
     L.chmc_profile_enable(0 if a.no_profile else (1 << dom if dom > 0 else 1))
     L.chmc_profile_stride(a.profile_stride)  # events around every n-th launch of the dominant kernel
     stats = []
@@ -161,13 +283,13 @@ def main():
 
     gather_segment()  # untimed: first use loads torch's copy / cat kernels and sets up the communicator's buffers
     D.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     run_steps(a.steps, stats)
     t_steps = time.perf_counter() - t0
     samples = gather_segment()
     D.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if os.environ.get("CHMC_BENCH_VERBOSE"):
         print(f"[rank {rank}] steps {t_steps * 1e3:.1f} ms, gather + sync {(elapsed - t_steps) * 1e3:.1f} ms", file=sys.stderr)
@@ -177,78 +299,110 @@ def main():
     L.chmc_profile_enable(0)
     L.chmc_profile_stride(1)
     t_max = D.max_over_ranks(elapsed)
+    per_rank = D.gather_samples(np.array([[elapsed * 1e3]]), equal_shards=True)
 
     status = np.stack([s["status"] for s in stats])
     okm = status == 0
     itf = np.stack([s["iters_fwd"] for s in stats])
     itb = np.stack([s["iters_bwd"] for s in stats])
     k_mean = float((itf[okm] + itb[okm]).mean()) if okm.any() else float("nan")
-    agg = D.sum_over_ranks([okm.sum(), status.size, itf.sum() + itb.sum()])
-    out = None
+    agg = D.sum_over_ranks([okm.sum(), status.size, itf.sum() + itb.sum(), 1.0])
     if rank == 0:
         total_steps = world * B * a.steps
         value = total_steps / t_max
-        # dominant kernel (largest accumulated device time) and its roofline figure
-        name = _lib.KERNEL_CLASSES[dom]
-        avg_ms = ms[dom] / max(nl[dom], 1) if nl[dom] else float("nan")
-        nnz, Q = wl.nnz(), ctx.Q
-        # algorithmic bytes per chain of one launch of each block kernel (SURVEY.md 8d operator decomposition):
-        #   newton_blk = constr (Q) + jacob_constr_blocks (Q + nnz written) + lu_jacob_product_blocks (2 nnz)
-        #   state_blk  = constr (Q) + jacob (Q + nnz) + chol_gram_blocks (nnz)
-        #   grad_log_det_blk = 4 nnz + 2 Q;  update = nnz + 6 Q;  jacob_vec = nnz + Q
-        per_chain = {"newton_blk": 8.0 * (3 * nnz + 2 * Q), "state_blk": 8.0 * (2 * nnz + 2 * Q),
-                     "grad_log_det_blk": 8.0 * (4 * nnz + 2 * Q), "update": 8.0 * (nnz + 6 * Q),
-                     "jacob_vec": 8.0 * (nnz + Q)}.get(name, 8.0 * 3 * Q)
+        cm = class_model(ctx, wl, model, wl.solver["newton"])
+        # measured HBM bytes per launch of every class (two separate rocprofv3 --pmc passes, tools/pmc_summary.py);
+        # only quoted when the file was produced by THIS build of the library
+        traffic_all, traffic_note = {}, "profiles/traffic.json absent"
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf) and not emu:
+            try:
+                tj = json.load(open(tf))
+                if tj.get("_lib_sha256") == lib_sha256() and tj.get("_config", "fhn_noisy") == a.config:
+                    traffic_all, traffic_note = tj, f"profiles/traffic.json ({tj.get('_command', 'rocprofv3 --pmc passes')}), same library build"
+                else:
+                    traffic_note = "profiles/traffic.json is from another build or configuration: not quoted"
+            except Exception as e:  # noqa: BLE001
+                traffic_note = f"profiles/traffic.json unreadable ({e})"
         # chains one launch processes: the Newton-loop kernels are masked per chain, so the later iterations of a solve
         # (and the one speculatively enqueued iteration that finds every chain converged) touch only the chains still
         # active.  For newton_blk the (chain, iteration) pairs of the timed region are known exactly from the
         # per-chain iteration counters; the other classes run over every chain.
+        name = _lib.KERNEL_CLASSES[dom]
+        avg_ms = ms[dom] / max(nl[dom], 1) if nl[dom] else float("nan")
         launches_all = nl[dom] * a.profile_stride
         if name == "newton_blk" and nl[dom]:
             chains_per_launch = float(itf.sum() + itb.sum()) / launches_all
         else:
             chains_per_launch = float(B)
-        achieved = per_chain * chains_per_launch / (avg_ms * 1e-3) / 1e9 if nl[dom] else float("nan")
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(name)
-            except Exception:
-                traffic = None
+        mdl = cm.get(name, dict(bytes=8.0 * 3 * ctx.Q, flops=2.0 * ctx.Q))
+        bound = BOUND.get(name, "hbm")
+        traffic = traffic_all.get(name)
+        alg_bytes = mdl["bytes"] * chains_per_launch
+        alg_flops = mdl["flops"] * chains_per_launch
+        sec = avg_ms * 1e-3
+        if bound == "hbm":
+            achieved, peak, unit = alg_bytes / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:  # fp64_valu: algorithmic fp64 flops of the launch against the fp64 vector peak
+            achieved, peak, unit = alg_flops / sec / 1e12, FP64_VALU_PEAK_TFLOPS, "TFLOP/s"
+        roofline = {
+            "bound": bound if bound != "latency" else "fp64_valu", "kernel": name, "achieved": achieved, "peak": peak,
+            "unit": unit, "frac": achieved / peak, "traffic": traffic,
+            "hbm_traffic_frac": (traffic / sec / 1e9 / HBM_PEAK_GBS) if traffic else None, "traffic_source": traffic_note,
+            "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
+            "algorithmic_bytes_GBs": alg_bytes / sec / 1e9,
+            "chains_per_launch": chains_per_launch, "avg_launch_ms": avg_ms, "launches_timed": int(nl[dom]),
+            "timed_every": a.profile_stride,
+            "note": "achieved = algorithmic fp64 flops (SURVEY.md 8d: Jacobian sweep + Gram contraction of the launch's "
+                    "chains) / average launch time by HIP events on the library's stream; the kernel regenerates the "
+                    "iterate's Jacobian in registers and is bound by fp64 vector issue, not by HBM (`hbm_traffic_frac` "
+                    "= measured HBM bytes / time / 8 TB/s); `algorithmic_bytes_GBs` is the operator-level byte rate of "
+                    "SURVEY.md 8d, a throughput figure that is NOT a DRAM utilisation (the fused kernel never moves "
+                    "those bytes)" if bound != "hbm" else
+                    "achieved = algorithmic bytes (SURVEY.md 8d) / average launch time by HIP events on the library's stream",
+        }
+        # the whole step attributed: every class with its time, binding resource and fraction of that resource's peak
+        table = {}
+        for i, k in enumerate(_lib.KERNEL_CLASSES):
+            if not nl_w[i]:
+                continue
+            per_launch = ms_w[i] / nl_w[i]
+            row = {"ms_per_step": round(ms_w[i] / max(a.warmup, 1), 3), "ms_per_launch": round(per_launch, 4),
+                   "launches_per_step": round(nl_w[i] / max(a.warmup, 1), 1), "bound": BOUND.get(k, "latency")}
+            if k in cm:
+                row["compulsory_bytes_per_chain"] = cm[k]["bytes"]
+                if BOUND.get(k) == "hbm" and k != "update":  # (update launches are masked: chains per launch unknown here)
+                    row["frac_of_hbm_peak"] = round(cm[k]["bytes"] * B / (per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
+                if BOUND.get(k) == "fp64_valu" and k not in ("newton_blk", "constr"):
+                    row["frac_of_fp64_peak"] = round(cm[k]["flops"] * B / (per_launch * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS, 3)
+            if traffic_all.get(k):
+                row["counter_bytes_per_launch"] = traffic_all[k]
+                row["hbm_traffic_frac"] = round(traffic_all[k] / (per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
+            table[k] = row
         out = {
             "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": t_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not emu else "emu-rehearsal (TEST ONLY, no GPU)",
             "config": {
-                "workload": f"FHN noisy-obs, T=100 obs, S={a.num_steps_per_obs} steps/obs, R=5 obs/subseq, sigma_y=0.1, "
-                            f"{B} chains per GPU (BASELINE.json configs[1]), Newton solver, standard splitting",
-                "chains_per_gpu": B, "global_chains": world * B, "dim_q": Q, "step_size": a.step_size,
-                "traj_len": a.traj_len, "parallelism": f"chains x{world} (no data-path collective, 1 gather)",
+                "workload": workload, "chains_per_gpu": B, "global_chains": world * B, "dim_q": ctx.Q,
+                "step_size": step_size, "traj_len": a.traj_len,
+                "parallelism": f"chains x{world} (no data-path collective, 1 gather)",
+                "ranks_joined": int(agg[3]), "per_rank_ms": None if per_rank is None else [round(float(x), 2) for x in per_rank[:, 0]],
                 "mean_newton_iters_fwd_plus_bwd": k_mean, "step_success_rate": float(agg[0] / agg[1]),
                 "gathered_sample_shape": None if samples is None else list(samples.shape),
-                "bytes_per_chain_step_algorithmic": wl.bytes_per_chain_step(k_mean),
-                "whole_path_effective_GBs": wl.bytes_per_chain_step(k_mean) * value / 1e9,
-                "warmup_kernel_ms_per_launch": {k: round(ms_w[i] / nl_w[i], 4) for i, k in enumerate(_lib.KERNEL_CLASSES) if nl_w[i]},
-                "warmup_kernel_ms_per_step": {k: round(ms_w[i] / max(a.warmup, 1), 3) for i, k in enumerate(_lib.KERNEL_CLASSES) if nl_w[i]},
+                "bytes_per_chain_step_algorithmic": wl.bytes_per_chain_step(k_mean, newton=wl.solver["newton"]),
+                "whole_path_effective_GBs": wl.bytes_per_chain_step(k_mean, newton=wl.solver["newton"]) * value / 1e9,
+                "overlap_halves": int(os.environ.get("CHMC_HALVES", "-1")),
+                "kernel_classes_warmup": table,
             },
-            "roofline": {"bound": "hbm", "kernel": name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": per_chain * chains_per_launch,
-                         "algorithmic_bytes_per_chain": per_chain, "chains_per_launch": chains_per_launch,
-                         "avg_launch_ms": avg_ms,
-                         "launches_timed": int(nl[dom]), "timed_every": a.profile_stride,
-                         "hbm_traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                         "note": "achieved = operator-level algorithmic bytes (SURVEY.md 8d) / launch time; the kernel "
-                                 "never materialises the iterate's Jacobian, so this can exceed the HBM peak; "
-                                 "`traffic` is the measured HBM bytes per launch (PMC), `hbm_traffic_frac` its rate "
-                                 "against the peak (the kernel is bound by fp64 VALU issue, DESIGN.md section 4)"},
+            "roofline": roofline,
         }
         if world == 1 and not a.no_cpu_baseline:
             q, p, xo, part = ctx.get_state()
-            out["cpu_baseline"] = cpu_baseline(wl, q, p, xo, part, a.step_size, a.cpu_steps, wl.solver)
+            n_cpu = a.cpu_steps if a.cpu_steps is not None else (250 if model == "fhn" and S >= 400 else 400)
+            out["cpu_baseline"] = cpu_baseline(wl, model, q, p, xo, part, step_size, n_cpu, wl.solver, gaussian)
             out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        print(json.dumps(_finite(out)), flush=True)
     D.barrier()
     ctx.close()
     if world > 1:

@@ -6,6 +6,9 @@ from .context import ChmcContext
 from .init import fhn_initial_states, fhn_initial_states_device
 
 SEED = 20200710  # scripts/utils.py:75-77
+# daily counts of the boarding-school influenza outbreak (the reference's scripts/sir_model_boarding_school_data.npz,
+# loaded at scripts/sir_model_chmc_experiment.py:62-64; obs_interval 1.0)
+BOARDING_SCHOOL_COUNTS = (3, 8, 28, 75, 221, 281, 255, 235, 190, 125, 70, 28, 12, 5)
 
 
 class FhnWorkload:
@@ -59,13 +62,39 @@ class FhnWorkload:
     def step(self, dt, active=None):
         return self.ctx.leapfrog_step(dt, active=active, **self.solver)
 
-    def bytes_per_chain_step(self, k_iters, partition=None):
-        """Algorithmic bytes of one chain-step, SURVEY.md section 8(d): 8 [k (4 nnz + 8 Q) + 10 nnz + 25 Q]."""
+    def bytes_per_chain_step(self, k_iters, partition=None, newton=True):
+        """Algorithmic bytes of one chain-step, SURVEY.md section 8(d): 8 [k (4 nnz + 8 Q) + 10 nnz + 25 Q]
+        (quasi-Newton: k (nnz + 7 Q) instead of the Newton term)."""
         nnz = self.nnz(partition)
-        return 8.0 * (k_iters * (4 * nnz + 8 * self.ctx.Q) + 10 * nnz + 25 * self.ctx.Q)
+        it = (4 * nnz + 8 * self.ctx.Q) if newton else (nnz + 7 * self.ctx.Q)
+        return 8.0 * (k_iters * it + 10 * nnz + 25 * self.ctx.Q)
 
     def nnz(self, partition=None):
         c = self.ctx
         p = c.partition if partition is None else partition
         return (c.C[p] * c.U + sum(b["nrows"] * b["ncols"] for b in c.blocks[p])
                 + (c.T if c.noisy else 0))
+
+
+class SirWorkload(FhnWorkload):
+    """SIR chains on the boarding-school data as scripts/sir_model_chmc_experiment.py sets them up (BASELINE.json
+    configs[3]): 14 daily counts, S steps per observation, ONE sub-sequence of R = 14 observations (dense 14 x 14 Gram
+    block), sigma_y = 1, initial states by the Adam-based finder of the noisy system (sde/mici_extensions.py:1679-1801)
+    with one generator for the whole batch (the finder restarts chains, so draws are not chain-indexed)."""
+
+    def __init__(self, num_chains, num_steps_per_obs=200, sigma=1.0, device=0, chain_offset=0, total_chains=None,
+                 use_gaussian_splitting=False, seed=SEED, adam_step_size=1e-1, log=None):
+        from . import init
+        self.B, self.S, self.T, self.R = num_chains, num_steps_per_obs, len(BOARDING_SCHOOL_COUNTS), len(BOARDING_SCHOOL_COUNTS)
+        self.sigma, self.obs_interval = sigma, 1.0
+        self.seed, self.chain_offset = seed, chain_offset
+        self.y = np.asarray(BOARDING_SCHOOL_COUNTS, dtype=np.float64).reshape(-1, 1)
+        self.ctx = ChmcContext("sir", self.obs_interval, num_steps_per_obs, self.R, self.y[:, 0], sigma=sigma,
+                               use_gaussian_splitting=use_gaussian_splitting, num_chains=num_chains, device=device)
+        rng = np.random.default_rng(np.random.SeedSequence(seed).spawn(chain_offset + 1)[chain_offset])
+        _, _, self.init_tries = init.find_initial_states_by_gradient_descent_noisy_system(
+            self.ctx, rng, adam_step_size=adam_step_size, max_iters=5000, log=log)
+        self.rngs = [rng]
+        self.solver = dict(newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10, max_iters=50,
+                           reverse_check_tol=2e-8)
+        self._torch_gen = None

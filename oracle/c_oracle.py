@@ -15,6 +15,12 @@ dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int)
 
 
+PORTABLE_CFLAGS = "-O2 -std=c99 -fPIC"          # oracle/c/Makefile: the build every parity test uses (no FMA contraction)
+NATIVE_CFLAGS = "-O3 -march=native -std=c99 -fPIC"  # bench.py's cpu_baseline: the strongest single-source CPU build
+CFLAGS = PORTABLE_CFLAGS
+_libs = {}
+
+
 def build(force=False):
     """Compile the C oracle with gcc (seconds)."""
     src = os.path.join(_HERE, "c", "chmc_oracle.c")
@@ -23,11 +29,46 @@ def build(force=False):
     return _SO
 
 
+def build_native():
+    """-O3 -march=native build for the CPU-baseline timing, compiled ON the machine that runs it (keyed by that
+    machine's CPU flags, so a library built elsewhere is never loaded)."""
+    import hashlib
+    flags = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            flags = next((ln for ln in f if ln.startswith("flags")), "")
+    except OSError:
+        pass
+    d = os.path.join(_HERE, "c", "_native")
+    os.makedirs(d, exist_ok=True)
+    so = os.path.join(d, "libchmc_oracle_%s.so" % hashlib.sha1(flags.encode()).hexdigest()[:12])
+    src = os.path.join(_HERE, "c", "chmc_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["gcc"] + NATIVE_CFLAGS.split() + ["-Wno-unused-function", "-Wno-unused-variable", "-shared",
+                               "-o", so, src, "-lm"])
+    return so
+
+
+def select_build(kind):
+    """"portable" (default; parity tests) or "native" (CPU-baseline timing): which library lib() hands out from now on."""
+    global _lib, CFLAGS
+    if kind not in ("portable", "native"):
+        raise ValueError(kind)
+    if kind not in _libs:
+        _libs[kind] = _load(build() if kind == "portable" else build_native())
+    _lib = _libs[kind]
+    CFLAGS = PORTABLE_CFLAGS if kind == "portable" else NATIVE_CFLAGS
+
+
 def lib():
-    global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_SO)
+        select_build("portable")
+    return _lib
+
+
+def _load(path):
+    if True:
+        L = C.CDLL(path)
         L.orc_create.restype = C.c_void_p
         L.orc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, dp]
         L.orc_destroy.argtypes = [C.c_void_p]
@@ -63,8 +104,7 @@ def lib():
         L.orc_chain_step.restype = C.c_int
         L.orc_chain_step.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                      C.c_int, C.c_double, ip, ip, dp]
-        _lib = L
-    return _lib
+    return L
 
 
 def _d(a):
