@@ -281,6 +281,7 @@ def main():
         ham = torch.from_numpy(ctx.hamiltonian()[:, :1]).to(dev)
         return D.gather_samples(torch.cat([qd[:, :6], ham], 1).contiguous(), equal_shards=True)
 
+    iters_before = ctx.counters()["projection_iterations"]
     gather_segment()  # untimed: first use loads torch's copy / cat kernels and sets up the communicator's buffers
     D.barrier()
     sync()
@@ -331,8 +332,14 @@ def main():
         name = _lib.KERNEL_CLASSES[dom]
         avg_ms = ms[dom] / max(nl[dom], 1) if nl[dom] else float("nan")
         launches_all = nl[dom] * a.profile_stride
+        pairs = float(itf.sum() + itb.sum())  # (chain, Newton iteration) pairs of the timed region
         if name == "newton_blk" and nl[dom]:
-            chains_per_launch = float(itf.sum() + itb.sum()) / launches_all
+            chains_per_launch = pairs / launches_all
+        elif name in ("update", "constr", "solve_chain", "sym_blk") and nl[dom]:
+            # one masked launch per Newton / quasi-Newton iteration (the chains still iterating) plus the launches
+            # that run over every chain (state evaluation, momentum projections)
+            full = max(launches_all - float(ctx.counters()["projection_iterations"] - iters_before), 0.0)
+            chains_per_launch = (pairs + B * full) / launches_all
         else:
             chains_per_launch = float(B)
         mdl = cm.get(name, dict(bytes=8.0 * 3 * ctx.Q, flops=2.0 * ctx.Q))

@@ -104,6 +104,19 @@ def run(num_chains=64, n_iter=700, n_warm=200, n_step=24, out_dir=None, seed=202
     tr = {k: np.load(f) for k, f in res["trace_files"].items()}
     moving = (np.diff(tr["σ"][:, n_warm:], axis=1) != 0).mean(1) >= 0.1
     sm = summarize({k: v[moving][:, n_warm:] for k, v in tr.items()})
+    if verbose and not moving.all():
+        # diagnosis of the chains left out: where their parameters sit and how their transitions ended
+        sm_all = summarize({k: v[:, n_warm:] for k, v in tr.items()})
+        print("chains left out of the summary (moved in < 10 % of the main transitions):")
+        oc = res.get("chain_outcomes")
+        for c in np.flatnonzero(~moving):
+            line = f"  chain {c:3d}: sigma {tr['σ'][c, -1]:.3f} eps {tr['ϵ'][c, -1]:.4f} gamma {tr['γ'][c, -1]:.3f} beta {tr['β'][c, -1]:.3f}"
+            if oc is not None:
+                line += ("  transitions: accepted %d, rejected %d, not converged %d, diverged %d, non-reversible %d"
+                         % tuple(oc[c]))
+            print(line)
+        print("  posterior means over ALL chains (no selection): " + ", ".join(
+            f"{k} {sm_all['mean'][k]:.3f}" for k in ("σ", "ϵ", "γ", "β", "x_0[0]", "x_0[1]")))
     rows = []
     for k in ("σ", "ϵ", "γ", "β", "x_0[0]", "x_0[1]"):
         mc = sm["sd"][k] / np.sqrt(max(sm["ess_bulk"][k], 1.0))

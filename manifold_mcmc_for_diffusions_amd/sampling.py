@@ -89,6 +89,9 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
         n_skip = min(int(metric_skip * n_adapt), n_metric - 2)
         n_head = max(n_head, ctx.U)
     stuck = np.zeros(B, dtype=np.int64)  # consecutive trajectories with zero acceptance probability
+    # per chain: how its post-warm-up transitions ended: [accepted, rejected after a complete trajectory, retraction did
+    # not converge (status 1), diverged (2), non-reversible step (3)] -- the diagnosis of a chain that does not move
+    outcome = np.zeros((B, 5), dtype=np.int64)
     heads = np.empty((n_iter, B, n_head))
     acc_hist, eps_hist, fail_hist = np.empty(n_iter), np.empty(n_iter), np.empty(n_iter)
     if trace_func is None:
@@ -109,18 +112,23 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
         dt = np.where(draw() < 0.5, step_size, -step_size) * scale
         act = np.ones(B, dtype=np.int32)
         length = 1 + np.floor(draw() * n_step).astype(np.int64) if jitter_length else np.full(B, n_step)
+        end_status = np.zeros(B, dtype=np.int64)
         for k in range(n_step):
             run = (act == 1) & (k < length)
             if not run.any():
                 break
             r = ctx.leapfrog_step(dt, active=run.astype(np.int32), **solver)
             bad = run & (r["status"] != 0)
+            end_status = np.where(bad, r["status"], end_status)
             act &= (~bad).astype(np.int32)
         h1 = ctx.hamiltonian()[:, 0]
         dh = h1 - h0
         prob = np.where((act == 1) & np.isfinite(dh), np.exp(np.minimum(0.0, -np.where(np.isfinite(dh), dh, np.inf))), 0.0)
         accept = draw() < prob
         stuck = np.where(prob > 0.0, 0, stuck + 1)
+        if it >= n_adapt:
+            col = np.where(end_status > 0, 1 + np.clip(end_status, 1, 3), np.where(accept, 0, 1))
+            outcome[np.arange(B), col] += 1
         ctx.restore((~accept).astype(np.int32))
         ctx.switch_partition()
         heads[it] = ctx.get_head(n_head)
@@ -145,7 +153,8 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
                 step_size = adapter.final()
         if callback is not None:
             callback(it, heads[it], prob.mean(), step_size)
-    out = dict(heads=heads, accept_stat=acc_hist, step_size=eps_hist, fail_rate=fail_hist, final_step_size=step_size)
+    out = dict(heads=heads, accept_stat=acc_hist, step_size=eps_hist, fail_rate=fail_hist, final_step_size=step_size,
+               chain_outcomes=outcome)
     if n_metric:
         out["metric_M_0"] = None if ctx.M_0 is None else ctx.M_0.copy()
     if writer is not None:

@@ -59,6 +59,22 @@ class FhnModel:
         return v_0 - torch.stack([torch.zeros((), dtype=DT), z[3]])
 
 
+class FhnNbModel(FhnModel):
+    """The FitzHugh-Nagumo model as the reference's notebook sets it up (FitzHugh-Nagumo_example.ipynb cells 7-18):
+    drift, diffusion coefficient and strong-order-1.5 step of fhn.py, with the notebook's own priors."""
+
+    name = "fhn_nb"
+    model_id = 2
+
+    @staticmethod
+    def generate_z(u):  # notebook cell 18
+        return torch.stack([torch.exp(0.5 * u[0] - 1), torch.exp(0.5 * u[1] - 2), 0.5 * u[2] + 1, 0.5 * u[3] + 1])
+
+    @staticmethod
+    def generate_x_0(z, v_0):  # notebook cell 18
+        return v_0 - 0.5
+
+
 class SirModel:
     """sde/example_models/sir.py"""
 
@@ -131,5 +147,6 @@ class SirModel:
 
 
 fhn = FhnModel
+fhn_nb = FhnNbModel
 sir = SirModel
-MODELS = {"fhn": fhn, "sir": sir}
+MODELS = {"fhn": fhn, "sir": sir, "fhn_nb": fhn_nb}

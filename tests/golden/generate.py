@@ -26,6 +26,9 @@ CASES = [
     ("fhn_noisy_r5", "fhn", 12, 6, 5, True, False, 0.2),
     ("sir_single_block", "sir", 5, 6, None, True, False, 0.25),
     ("sir_partitioned", "sir", 6, 8, 2, True, False, 0.25),
+    # the notebook's model (FitzHugh-Nagumo_example.ipynb): noiseless observations every 0.5, Gaussian splitting, R = 5
+    ("fhn_nb_noiseless_gauss", "fhn_nb", 7, 25, 5, False, True, 0.5),
+    ("fhn_nb_noisy_std", "fhn_nb", 6, 4, 2, True, False, 0.2),
 ]
 TOLS = dict(constraint_tol=1e-9, position_tol=1e-8, max_iters=50)
 
@@ -60,10 +63,13 @@ def pad_chol(chol, rmax):
 
 
 def main():
+    only = set(sys.argv[1:])  # regenerate only the named cases (the committed files of the others stay as they are)
     for name, mname, T, S, R, noisy, gaussian, oi in CASES:
+        if only and name not in only:
+            continue
         rng = np.random.default_rng(11 if mname == "sir" else sum(map(ord, name)))
         model = omodels.MODELS[mname]
-        sigma = (0.1 if mname == "fhn" else 1.0) if noisy else None
+        sigma = (0.1 if mname in ("fhn", "fhn_nb") else 1.0) if noisy else None
         q = random_q(mname, T, S, noisy, 1, rng)[0]
         sys0 = osys.make_system(model, oi, S, R, np.zeros((T, 1)), sigma=sigma, use_gaussian_splitting=gaussian)
         xo = sys0._generate_x_obs_seq(osys.T(q)).numpy()

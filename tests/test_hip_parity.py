@@ -386,3 +386,92 @@ def test_tree_leaf(model, T, S, R, noisy, with_metric):
     ctx = make_ctx(case)
     check_tree_leaf(ctx, case, "cuda", with_metric)
     ctx.close()
+
+
+def _distinct_on_manifold_chains(model, T, S, R, B, seed, obs_interval=None):
+    """B DIFFERENT chain states that all lie on the constraint manifold of one noisy-observation data set: every chain
+    has its own (u, v_0, v_seq); x_obs_seq is its own trajectory (state rows vanish) and its observation-noise
+    components are solved for, n_t = (y_t - obs_func(x_t)) / sigma (observation rows vanish)."""
+    from manifold_mcmc_for_diffusions_amd import example_models as em
+    case = make_case(model, T, S, R, True, B=B, seed=seed, obs_interval=obs_interval)
+    m, q, xo, y, sigma = em.MODELS[model], case["q"], case["x_obs"], case["y"], case["sigma"]
+    q[:, -T:] = (y[None, :] - m.obs_func(xo)[..., 0]) / sigma
+    return case
+
+
+def test_full_size_distinct_chains_with_masked_subset():
+    """BASELINE.json configs[1] at full size (Q = 80106) with 72 DISTINCT chains (more than one wavefront of chains,
+    B K = 1440 / 1512 blocks: full and partial wavefronts of every kernel), a subset masked out by `active`, two chains
+    whose retraction cannot converge (masked inside the Newton loop from then on) -- every chain against the C oracle,
+    in both partitions."""
+    from oracle import c_oracle
+    B = 72
+    case = _distinct_on_manifold_chains("fhn", 100, 400, 5, B, seed=71)
+    ctx = make_ctx(case)
+    assert ctx.Q == 80106
+    rng = case["rng"]
+    inactive, failing = [5, 17, 33, 64, 71], [7, 40]
+    for part in (0, 1):
+        ctx.set_state(case["q"], rng.standard_normal((B, ctx.Q)), case["x_obs"], part)
+        assert np.abs(ctx.constr()).max() < 1e-9
+        ctx.project_onto_cotangent_space()
+        q0, p0, _, _ = ctx.get_state()
+        dts = np.where(np.arange(B) % 2 == 0, 1.0, -1.0) * (0.02 + 0.04 * rng.random(B))
+        dts[failing] = 5.0
+        act = np.ones(B, dtype=np.int32)
+        act[inactive] = 0
+        res = ctx.leapfrog_step(dts, active=act, max_iters=12)
+        q1, p1, _, _ = ctx.get_state()
+        assert (res["status"][inactive] == -1).all() and (res["status"][failing] > 0).all()
+        n_ok = 0
+        for c in range(B):
+            if not act[c]:
+                assert np.array_equal(q1[c], q0[c]) and np.array_equal(p1[c], p0[c])
+                continue
+            ch = c_oracle.OracleChain(case["osys"])
+            ch.set(case["q"][c], p0[c], case["x_obs"][c], part)
+            st, itf, itb, _ = ch.step(dts[c], max_iters=12)
+            qo, po, _, _ = ch.get()
+            assert res["status"][c] == st, (part, c, res["status"][c], st)
+            assert res["iters_fwd"][c] == itf and (st != 0 or res["iters_bwd"][c] == itb), (part, c)
+            assert np.abs(q1[c] - qo).max() <= 1e-9 * max(1.0, np.abs(qo).max()), (part, c)
+            assert np.abs(p1[c] - po).max() <= 1e-9 * max(1.0, np.abs(po).max()), (part, c)
+            n_ok += st == 0
+        assert n_ok >= B - len(inactive) - len(failing) - 3
+    ctx.close()
+
+
+def test_sir_boarding_school_s200_adam_init_against_oracle():
+    """BASELINE.json configs[3] as scripts/sir_model_chmc_experiment.py sets it up: the boarding-school counts, S = 200,
+    ONE sub-sequence of R = 14 observations (16-row kernels), sigma_y = 1, initial states by the Adam-based finder of the
+    noisy system (sde/mici_extensions.py:1679-1801) run on the library's operators.  The found states must lie on the
+    manifold; every per-op entry point and one leapfrog step are checked against the C oracle AT those states."""
+    from oracle import c_oracle
+    from manifold_mcmc_for_diffusions_amd.workload import SirWorkload
+    B = 6
+    wl = SirWorkload(B, num_steps_per_obs=200)
+    ctx = wl.ctx
+    assert ctx.Q == 8419 and ctx.C == [14] and ctx.K == [1] and ctx.RM == 16
+    assert np.abs(ctx.constr()).max() < 1e-9
+    q, _, xo, _ = ctx.get_state()
+    assert (np.mean(q[:, -14:] ** 2, 1) < 1.0).all()  # the finder's acceptance threshold on the mean squared residual
+    osys = c_oracle.OracleSystem("sir", 1.0, 200, 14, wl.y[:, 0], sigma=1.0)
+    case = dict(osys=osys, q=q, x_obs=xo, B=B, rng=np.random.default_rng(5))
+    check_ops_against_oracle(ctx, case, tol=1e-9)
+    # one leapfrog step of every chain from ITS OWN state
+    ctx.set_state(q, case["rng"].standard_normal((B, ctx.Q)), xo, 0)
+    ctx.project_onto_cotangent_space()
+    _, p0, _, _ = ctx.get_state()
+    dts = np.array([0.05, -0.05, 0.1, -0.1, 0.02, 0.2])
+    res = ctx.leapfrog_step(dts)
+    q1, p1, _, _ = ctx.get_state()
+    for c in range(B):
+        ch = c_oracle.OracleChain(osys)
+        ch.set(q[c], p0[c], xo[c], 0)
+        st, itf, itb, _ = ch.step(dts[c])
+        qo, po, _, _ = ch.get()
+        assert res["status"][c] == st and res["iters_fwd"][c] == itf and (st != 0 or res["iters_bwd"][c] == itb)
+        assert np.abs(q1[c] - qo).max() <= 1e-9 * max(1.0, np.abs(qo).max())
+        assert np.abs(p1[c] - po).max() <= 1e-9 * max(1.0, np.abs(po).max())
+    assert (res["status"] == 0).sum() >= 4
+    ctx.close()

@@ -12,7 +12,7 @@ from manifold_mcmc_for_diffusions_amd import example_models as em
 from helpers import make_case, random_q
 
 
-@pytest.mark.parametrize("model", ["fhn", "sir"])
+@pytest.mark.parametrize("model", ["fhn", "sir", "fhn_nb"])
 def test_one_step_maps_agree(model):
     rng = np.random.default_rng(0)
     m_t, m_n = omodels.MODELS[model], em.MODELS[model]
@@ -60,7 +60,9 @@ def rowslot(osy, jac):
 
 
 CASES = [("fhn", 6, 4, 2, True, False), ("fhn", 7, 5, 3, False, True), ("fhn", 9, 3, 4, True, False),
-         ("fhn", 5, 4, None, True, False), ("sir", 5, 6, None, True, False), ("sir", 6, 8, 2, True, False)]
+         ("fhn", 5, 4, None, True, False), ("sir", 5, 6, None, True, False), ("sir", 6, 8, 2, True, False),
+         # the notebook's model: the C side is generated code, the autodiff side the hand-written oracle/py/models.py
+         ("fhn_nb", 7, 5, 3, False, True), ("fhn_nb", 6, 4, 2, True, False)]
 
 
 @pytest.mark.parametrize("model,T,S,R,noisy,gaussian", CASES)

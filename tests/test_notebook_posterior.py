@@ -2,7 +2,9 @@
 FitzHugh-Nagumo_example.ipynb (tests/golden/reference_data/notebook_posterior_table.json).  The notebook's experiment
 is re-run on the GPU (same data from the same legacy seed, same model, priors, discretisation, splitting, solver and
 tolerances; a static-trajectory sampler instead of Mici's dynamic one, 64 chains instead of 2) and the posterior means
-must agree within Monte-Carlo error, the posterior standard deviations within 25 %."""
+must agree within Monte-Carlo error, the posterior standard deviations within 15 %.  Selection step (not in the
+reference, whose two chains were simply two usable prior draws): candidate starts are screened by a short pilot run and
+chains that move in fewer than 10 % of their main transitions are left out of the summary and counted."""
 import os
 import sys
 import numpy as np
@@ -31,8 +33,8 @@ def test_posterior_matches_the_notebook_table(tmp_path):
     assert n_moving >= 56                               # at most a few stuck starts
     assert 0.6 < res["accept_stat"][200:].mean() < 0.95
     for r in rows:
-        assert abs(r["z"]) < 4.0, r                     # means agree within Monte-Carlo error
-        assert 0.75 < r["sd"] / r["ref_sd"] < 1.25, r   # posterior spread agrees
+        assert abs(r["z"]) < 3.5, r                     # means agree within Monte-Carlo error
+        assert 0.85 < r["sd"] / r["ref_sd"] < 1.15, r   # posterior spread agrees
         assert r["r_hat"] < 1.1, r
 
 
@@ -50,6 +52,6 @@ def test_posterior_and_sampler_statistics_with_the_dynamic_transition(tmp_path):
     assert 15.0 < res["n_step"][150:].mean() < 45.0
     assert res["integrator_error"][150:].mean() < 0.4
     for r in rows:
-        assert abs(r["z"]) < 4.0, r
-        assert 0.75 < r["sd"] / r["ref_sd"] < 1.25, r
+        assert abs(r["z"]) < 3.5, r
+        assert 0.85 < r["sd"] / r["ref_sd"] < 1.15, r
         assert r["r_hat"] < 1.1, r
