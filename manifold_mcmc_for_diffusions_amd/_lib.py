@@ -9,7 +9,8 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_PKG, "libchmc_hip.so")
+# (CHMC_HIP_LIBRARY: another build of the SAME HIP library, for A/B measurements of kernel variants)
+_SO = os.environ.get("CHMC_HIP_LIBRARY") or os.path.join(_PKG, "libchmc_hip.so")
 _SRC = os.path.join(_PKG, "csrc")
 _LIB = None
 

@@ -4,7 +4,10 @@
 #include <hip/hip_runtime.h>
 
 // one stream per host thread that drives a context (contexts driven from different threads run concurrently)
+// g_stream is the stream every primitive below enqueues on: the main stream, or -- inside a leapfrog step that is run
+// as two half-batches (chmc_api.inc) -- one of the two half-batch streams selected with use_stream()
 static thread_local hipStream_t g_stream = nullptr;
+static thread_local hipStream_t g_streams[3] = {nullptr, nullptr, nullptr};  // main, half 0, half 1
 static thread_local int g_device = -1;
 static hipError_t g_first_err = hipSuccess;
 
@@ -31,14 +34,17 @@ static int dev_init(int device) {
     return -1;
   }
   if (dev_set(device)) return -1;
-  if (!g_stream || g_device != device) {
-    e = hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-      g_err = std::string("hipStreamCreate: ") + hipGetErrorString(e);
-      return -1;
+  if (!g_streams[0] || g_device != device) {
+    for (int i = 0; i < 3; ++i) {
+      e = hipStreamCreateWithFlags(&g_streams[i], hipStreamNonBlocking);
+      if (e != hipSuccess) {
+        g_err = std::string("hipStreamCreate: ") + hipGetErrorString(e);
+        return -1;
+      }
     }
     g_device = device;
   }
+  g_stream = g_streams[0];
   g_first_err = hipSuccess;
   return 0;
 }
@@ -61,13 +67,12 @@ static void d2h(void* h, const void* d, size_t bytes) {
 }
 // asynchronous read-back of one int (the Newton loop's active-chain count): the copy and an event are queued behind
 // the producing kernel, the host keeps enqueueing the next iteration and only then waits for the event
-static thread_local int* g_poll_host = nullptr;  // pinned, 2 slots
-static thread_local hipEvent_t g_poll_ev[2];
+static thread_local int* g_poll_host = nullptr;  // pinned, 4 slots (2 per half-batch)
+static thread_local hipEvent_t g_poll_ev[4];
 static void poll_begin(int slot, const int* d) {
   if (!g_poll_host) {
-    note(hipHostMalloc((void**)&g_poll_host, 2 * sizeof(int), hipHostMallocDefault));
-    note(hipEventCreateWithFlags(&g_poll_ev[0], hipEventDisableTiming));
-    note(hipEventCreateWithFlags(&g_poll_ev[1], hipEventDisableTiming));
+    note(hipHostMalloc((void**)&g_poll_host, 4 * sizeof(int), hipHostMallocDefault));
+    for (int i = 0; i < 4; ++i) note(hipEventCreateWithFlags(&g_poll_ev[i], hipEventDisableTiming));
   }
   note(hipMemcpyAsync(g_poll_host + slot, d, sizeof(int), hipMemcpyDeviceToHost, g_stream));
   note(hipEventRecord(g_poll_ev[slot], g_stream));
@@ -78,6 +83,50 @@ static int poll_end(int slot) {
 }
 static void d2d(void* dst, const void* src, size_t bytes) {
   note(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
+}
+// ---- two half-batches on two streams (chmc_leapfrog_step): fork / join against the main stream, and a ping-pong of
+// events that keeps the halves' latency-bound forward scans out of phase (half B's scan waits for half A's, A's next
+// one for B's), so that one half's scan and small kernels run under the other half's throughput-bound sweeps
+static const int kStagRing = 16;
+static thread_local hipEvent_t g_fork_ev = nullptr, g_join_ev[2], g_stag_ev[2][kStagRing];
+static thread_local int g_stag_n[2] = {0, 0};
+static thread_local int g_cur_half = -1;
+static void streams_init_events() {
+  if (g_fork_ev) return;
+  note(hipEventCreateWithFlags(&g_fork_ev, hipEventDisableTiming));
+  for (int h = 0; h < 2; ++h) {
+    note(hipEventCreateWithFlags(&g_join_ev[h], hipEventDisableTiming));
+    for (int i = 0; i < kStagRing; ++i) note(hipEventCreateWithFlags(&g_stag_ev[h][i], hipEventDisableTiming));
+  }
+}
+static void use_stream(int half) {  // -1: main stream
+  g_cur_half = half;
+  g_stream = g_streams[half + 1];
+}
+static void streams_fork() {
+  streams_init_events();
+  note(hipEventRecord(g_fork_ev, g_streams[0]));
+  for (int h = 0; h < 2; ++h) note(hipStreamWaitEvent(g_streams[h + 1], g_fork_ev, 0));
+  g_stag_n[0] = g_stag_n[1] = 0;
+}
+static void streams_join() {
+  for (int h = 0; h < 2; ++h) {
+    note(hipEventRecord(g_join_ev[h], g_streams[h + 1]));
+    note(hipStreamWaitEvent(g_streams[0], g_join_ev[h], 0));
+  }
+  use_stream(-1);
+}
+static const bool g_no_stagger = getenv("CHMC_NO_STAGGER") != nullptr;  // experiments: halves in phase
+static void stagger_wait() {  // before a forward scan of the current half: the other half's latest scan must be done
+  if (g_cur_half < 0 || g_no_stagger) return;
+  const int o = g_cur_half ^ 1;
+  if (g_stag_n[o] > 0) note(hipStreamWaitEvent(g_stream, g_stag_ev[o][(g_stag_n[o] - 1) % kStagRing], 0));
+}
+static void stagger_record() {
+  if (g_cur_half < 0 || g_no_stagger) return;
+  const int h = g_cur_half;
+  note(hipEventRecord(g_stag_ev[h][g_stag_n[h] % kStagRing], g_stream));
+  g_stag_n[h]++;
 }
 static int dev_sync() {
   note(hipStreamSynchronize(g_stream));
@@ -126,7 +175,8 @@ static hipEvent_t prof_event() {
 }
 static void prof_drain() {
   if (g_prof_pending.empty()) return;
-  note(hipStreamSynchronize(g_stream));
+  for (int i = 0; i < 3; ++i)
+    if (g_streams[i]) note(hipStreamSynchronize(g_streams[i]));
   for (auto& r : g_prof_pending) {
     float ms = 0.f;
     note(hipEventElapsedTime(&ms, r.a, r.b));

@@ -1334,11 +1334,20 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
   constexpr int NLD = PF * V / 2;        // 16-byte loads per lane and tile
   constexpr int NST = PF * X / 2;        // 16-byte chunks per trajectory row and tile
   constexpr int TBV = PF * V * 8;        // bytes of noise increments per tile
-  constexpr int DEPTH = V == 2 ? 4 : 3;  // tiles in flight
+#ifndef CHMC_SCAN_DEPTH
+#define CHMC_SCAN_DEPTH (V == 2 ? 4 : 3)
+#endif
+  constexpr int DEPTH = CHMC_SCAN_DEPTH;  // tiles in flight
   constexpr int NOUT = (DEPTH - 1) * NLD;
   constexpr int RSD = PF * X + 2;        // LDS row stride in doubles: tile + 16 bytes (conflict-free row access)
   static_assert(NOUT <= 63, "vmcnt is a 6-bit field");
-  __shared__ __attribute__((aligned(16))) double tile[STORE ? 2 : 1][STORE ? 64 * RSD : 2];
+#ifndef CHMC_SCAN_NB
+#define CHMC_SCAN_NB 1
+#endif
+  // NB tiles per hand-over: the integrating wave parks NB tiles before it meets the helper at the barrier, so the helper
+  // may fall up to NB tiles behind (store issue under memory load) without stalling the recursion
+  constexpr int NB = CHMC_SCAN_NB;
+  __shared__ __attribute__((aligned(16))) double tile[STORE ? 2 : 1][STORE ? NB * 64 * RSD : 2];
   __shared__ double obsv[64 * (2 * RM + 1)];
   const int lane = threadIdx.x & 63;
   const bool helper = STORE && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) != 0;
@@ -1383,21 +1392,33 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
         }
       }
     }
+#ifdef CHMC_SCAN_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     int buf = 0;
-    for (int st = 0; st < maxL; st += PF) {
-      lds_barrier();  // tile `st` is in tile[buf]
-      d2_t tt[NST];
+    for (int s0 = 0; s0 < maxL; s0 += PF * NB) {
+      lds_barrier();  // tiles s0 .. s0 + NB PF are in tile[buf]
 #pragma unroll
-      for (int i = 0; i < NST; ++i) tt[i] = *reinterpret_cast<const d2_t*>(&tile[buf][lo_[i]]);
+      for (int sl_ = 0; sl_ < NB; ++sl_) {
+        const int st = s0 + sl_ * PF;
+        if (st < maxL) {
+          d2_t tt[NST];
 #pragma unroll
-      for (int i = 0; i < NST; ++i)
-        if (st < rL[i]) vm_store16_nt(rp[i] + (size_t)st * X, tt[i]);
+          for (int i = 0; i < NST; ++i) tt[i] = *reinterpret_cast<const d2_t*>(&tile[buf][sl_ * 64 * RSD + lo_[i]]);
+#pragma unroll
+          for (int i = 0; i < NST; ++i)
+            if (st < rL[i]) vm_store16_nt(rp[i] + (size_t)st * X, tt[i]);
+        }
+      }
       buf ^= 1;
     }
     return;
   }
 
   // ---- integrating wave
+#ifdef CHMC_SCAN_PRIO
+  __builtin_amdgcn_s_setprio(3);
+#endif
   const int tid = tid0 + lane;
   const int tc = tid < n ? tid : n - 1;  // lanes past the end shadow the last block (valid addresses, no output)
   const int c = tc / sy.K, b = tc - c * sy.K;
@@ -1445,10 +1466,10 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
       if (st < maxL) {
         // ring[d] was refilled DEPTH tiles ago; DEPTH - 1 younger tiles may stay in flight
         vm_wait<NOUT>(ring[d]);
-        // hand the previous tile to the helper: its LDS writes were issued at least one step ago, so the wait is free
-        if (STORE && st > 0) lds_barrier();
+        // hand the previous NB tiles to the helper: their LDS writes were issued at least one step ago, so the wait is free
+        if (STORE && st > 0 && (st / PF) % NB == 0) lds_barrier();
         if (st < L) {
-          double* lo = STORE ? &tile[(st >> 3) & 1][lane * RSD] : nullptr;
+          double* lo = STORE ? &tile[((st / PF) / NB) & 1][((st / PF) % NB) * 64 * RSD + lane * RSD] : nullptr;
 #pragma unroll
           for (int i = 0; i < PF; ++i) {
             double vt[V];

@@ -13,7 +13,12 @@ static void h2d(void* d, const void* h, size_t bytes) { memcpy(d, h, bytes); }
 static void d2h(void* h, const void* d, size_t bytes) { memcpy(h, d, bytes); }
 static void d2d(void* dst, const void* src, size_t bytes) { memcpy(dst, src, bytes); }
 static int dev_sync() { return 0; }
-static int g_poll_val[2];
+static int g_poll_val[4];
+static void use_stream(int) {}
+static void streams_fork() {}
+static void streams_join() {}
+static void stagger_wait() {}
+static void stagger_record() {}
 static void poll_begin(int slot, const int* d) { g_poll_val[slot] = *d; }
 static int poll_end(int slot) { return g_poll_val[slot]; }
 template <class F>

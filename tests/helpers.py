@@ -233,3 +233,36 @@ def check_tree_leaf(ctx, case, device, with_metric):
         np.testing.assert_allclose(d_cs.cpu().numpy(), cs, rtol=0, atol=1e-14)
         np.testing.assert_allclose(crit, ecrit, rtol=1e-11, atol=1e-9)
     ctx.set_metric(None)
+
+
+def halves_vs_single_batch(case, monkeypatch, part=0, n_steps=2, newton=True, masked=(), failing=()):
+    """The same leapfrog steps with the step run as ONE batch (CHMC_HALVES=1) and as two overlapped half-batches on two
+    streams (CHMC_HALVES=2).  Chains are independent and every per-chain reduction has a fixed order, so the two runs
+    must agree BITWISE: positions, momenta, statuses, iteration counts, reverse-check distances."""
+    B = case["B"]
+    rng = np.random.default_rng(99)
+    p = rng.standard_normal(case["q"].shape)
+    qq = np.repeat(case["q"][:1], B, 0)
+    xx = np.repeat(case["x_obs"][:1], B, 0)
+    dts = np.where(np.arange(B) % 2 == 0, 1.0, -1.0) * (0.02 + 0.06 * rng.random(B))
+    dts[list(failing)] = 5.0
+    act = np.ones(B, dtype=np.int32)
+    act[list(masked)] = 0
+    out = []
+    for halves in ("1", "2"):
+        monkeypatch.setenv("CHMC_HALVES", halves)
+        ctx = make_ctx(case)
+        ctx.set_state(qq, p, xx, part)
+        res = []
+        for k in range(n_steps):  # first step from unprojected momenta (full projection path), then the shortcut
+            res.append(ctx.leapfrog_step(dts, active=act if k == 0 else None, newton=newton, max_iters=12))
+        q1, p1, _, _ = ctx.get_state()
+        out.append((q1, p1, res, ctx.hamiltonian()))
+        ctx.close()
+    a, b = out
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[3], b[3])
+    for ra, rb in zip(a[2], b[2]):
+        for k in ra:
+            assert np.array_equal(ra[k], rb[k]), k
+    assert (a[2][0]["status"][list(masked)] == -1).all() and (a[2][0]["status"][list(failing)] > 0).all()
+    return a

@@ -217,3 +217,14 @@ def test_tree_leaf(emu_lib, model, T, S, R, noisy, with_metric):
     ctx = make_ctx(case)
     check_tree_leaf(ctx, case, "cpu", with_metric)
     ctx.close()
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy,gaussian,newton", [
+    ("fhn", 12, 10, 5, True, False, True), ("fhn", 7, 5, 3, False, True, False), ("sir", 6, 8, 2, True, False, True)])
+def test_half_batches_equal_one_batch(emu_lib, monkeypatch, model, T, S, R, noisy, gaussian, newton):
+    """Host logic of the two-half-batch step (chain-range views, lock-step Newton loops, per-half counters) against the
+    one-batch step: bitwise equal, masked and failing chains in both halves."""
+    from helpers import halves_vs_single_batch
+    case = make_case(model, T, S, R, noisy, B=7, seed=81, gaussian=gaussian)
+    for part in range(2):
+        halves_vs_single_batch(case, monkeypatch, part=part, newton=newton, masked=(1, 6), failing=(2, 4))

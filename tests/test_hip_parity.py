@@ -475,3 +475,23 @@ def test_sir_boarding_school_s200_adam_init_against_oracle():
         assert np.abs(p1[c] - po).max() <= 1e-9 * max(1.0, np.abs(po).max())
     assert (res["status"] == 0).sum() >= 4
     ctx.close()
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy,gaussian,newton", [
+    ("fhn", 12, 16, 5, True, False, True), ("fhn", 7, 8, 3, False, True, True), ("fhn", 12, 10, 5, True, False, False),
+    ("sir", 14, 8, 14, True, False, True), ("sir", 6, 16, 2, True, False, True)])
+def test_half_batches_on_two_streams_equal_one_batch(monkeypatch, model, T, S, R, noisy, gaussian, newton):
+    """chmc_leapfrog_step as two overlapped half-batches (two streams, staggered forward scans, lock-step Newton loops)
+    against the same step as one batch: bitwise equal, with masked and failing chains in both halves (71 chains: odd
+    split 35 / 36, partial wavefronts)."""
+    from helpers import halves_vs_single_batch
+    case = make_case(model, T, S, R, noisy, B=71, seed=81, gaussian=gaussian)
+    for part in range(2 if R and R < T else 1):
+        halves_vs_single_batch(case, monkeypatch, part=part, newton=newton, masked=(3, 36, 70), failing=(5, 40))
+
+
+def test_half_batches_full_size(monkeypatch):
+    """The same at BASELINE.json configs[1]'s size (Q = 80106), 130 chains."""
+    from helpers import halves_vs_single_batch
+    case = make_case("fhn", 100, 400, 5, True, B=130, seed=82)
+    halves_vs_single_batch(case, monkeypatch, part=1, n_steps=2, masked=(0, 64, 65, 129), failing=(7, 100))
