@@ -155,9 +155,12 @@ int chmc_project(chmc_ctx* ctx, int newton, const double* q, const double* dt, d
                  double position_tol, double divergence_tol, int max_iters, double* q_out, double* mu_out,
                  int* iters, double* norm_dq, double* err, int* status);
 
-/* One ConstrainedLeapfrogIntegrator.step per chain (mici 0.1.10, n_inner_step == 1): A(dt/2) B(dt) A(dt/2) with
- * forward projection, reverse projection and reversibility check.  dt [B] = state.dir * step_size; active [B]
- * (NULL: all).  A chain whose step fails keeps its state (Mici discards the partial step).
+/* One ConstrainedLeapfrogIntegrator.step per chain (mici 0.1.10): A(dt/2) B(dt) A(dt/2); B = n_inner_step inner steps
+ * of dt / n_inner_step (scripts/utils.py:131-136 --num-inner-h2-step), each with forward projection, momentum
+ * projection at the new point, reverse projection and reversibility check; dh1_dpos is evaluated at the last new point
+ * only.  dt [B] = state.dir * step_size; active [B] (NULL: all).  A chain whose step fails -- in whichever inner step --
+ * keeps its state (Mici discards the partial step).  iters_fwd / iters_bwd are summed over the inner steps, rev_err is
+ * that of the last inner step a chain ran.
  * The two half-kicks A(dt/2): p <- P(q)[p - dt/2 dh1_dpos(q)] use the projected kick direction P(q) dh1_dpos(q) that
  * the library keeps with every evaluated state: for a momentum already in the cotangent space (after
  * chmc_sample_momentum, chmc_project_onto_cotangent_space or a previous step) P(q)[p - h g] = p - h P(q) g, which

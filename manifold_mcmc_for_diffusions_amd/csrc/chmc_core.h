@@ -1849,15 +1849,38 @@ struct KBegin {
   Work w;
   const int* active;
   const double* dt;
+  double scale;  // work.dt = scale * dt: the time step of one inner h2-flow step, dt / n_inner_step (mici _step_b)
   CHMC_HD void operator()(int c) const {
     w.ok[c] = active ? (active[c] != 0) : 1;
     w.status[c] = w.ok[c] ? 0 : -1;
     if (dt) {
-      w.dt[c] = dt[c];
-      w.sdt[c] = sin(dt[c]);
-      w.cdt[c] = cos(dt[c]);
+      const double h = scale * dt[c];
+      w.dt[c] = h;
+      w.sdt[c] = sin(h);
+      w.cdt[c] = cos(h);
     }
     w.rev[c] = 0ULL;
+  }
+};
+// n_inner_step > 1: accumulate the iteration counts of the inner steps; between inner steps the new point becomes
+// state_prev (mici _step_b: `state_prev = state.copy()`), i.e. the proposal slot becomes the state slot
+struct KAddIters {
+  Work w;
+  int* dst;
+  CHMC_HD void operator()(int c) const {
+    if (w.ok[c] || w.status[c] > 0) dst[c] += w.iters[c];  // (a chain that failed in this solve still reports its iterations)
+  }
+};
+struct KCommitInner {
+  Slots sl;
+  Work w;
+  int* ncommit;
+  CHMC_HD void operator()(int c) const {
+    if (w.ok[c]) {
+      sl.cur[c] ^= 1;
+      ncommit[c] += 1;
+      w.rev[c] = 0ULL;  // the reported reverse-check distance is that of the last inner step
+    }
   }
 };
 // One leaf of a dynamic (no-U-turn) trajectory tree, batched: everything the caller's tree bookkeeping needs from the

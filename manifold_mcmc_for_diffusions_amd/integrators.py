@@ -2,9 +2,10 @@
 the reference; call site scripts/utils.py:284-290), backed by the fused device step `chmc_leapfrog_step`.
 
 Two execution paths, same results:
-  * fused (default): when the projection solver is one of this package's two solvers and `n_inner_step == 1`
-    the whole A(dt/2) B(dt) A(dt/2) step runs on the device for all chains of the state at once;
-  * composed: any other configuration (custom solver callable, `n_inner_step > 1`) is composed on the host from
+  * fused (default): when the projection solver is one of this package's two solvers the whole
+    A(dt/2) B(dt) A(dt/2) step, with its `n_inner_step` inner h2-flow steps, runs on the device for all chains of the
+    state at once;
+  * composed: any other configuration (a custom solver callable or reverse-check norm) is composed on the host from
     the System methods exactly as Mici does, each of which calls the device library.
 With one chain numerical failures raise `ConvergenceError` / `NonReversibleStepError`; with a batch they are
 reported per chain in `state.step_status` (0 ok, 1 not converged, 2 diverged, 3 non-reversible) and a failed
@@ -36,7 +37,7 @@ class ConstrainedLeapfrogIntegrator:
 
     # ---- fused device path
     def _fusable(self):
-        return (self.n_inner_step == 1 and self.reverse_check_norm is maximum_norm and self.projection_solver in (
+        return (self.n_inner_step >= 1 and self.reverse_check_norm is maximum_norm and self.projection_solver in (
             jitted_solve_projection_onto_manifold_newton, jitted_solve_projection_onto_manifold_quasi_newton))
 
     def _step_fused(self, state):
@@ -46,7 +47,7 @@ class ConstrainedLeapfrogIntegrator:
         kw = self.projection_solver_kwargs
         dt = np.asarray(state.dir, dtype=np.float64) * self.step_size
         res = c.leapfrog_step(
-            dt, newton=self.projection_solver is jitted_solve_projection_onto_manifold_newton,
+            dt, n_inner_step=self.n_inner_step, newton=self.projection_solver is jitted_solve_projection_onto_manifold_newton,
             constraint_tol=kw.get("constraint_tol", 1e-8), position_tol=kw.get("position_tol", 1e-8),
             divergence_tol=kw.get("divergence_tol", 1e10), max_iters=kw.get("max_iters", 50),
             reverse_check_tol=self.reverse_check_tol)

@@ -98,7 +98,8 @@ def check_ops_against_oracle(ctx, case, tol=1e-10):
     return worst
 
 
-def check_steps_against_oracle(ctx, case, dts, newton=True, n_steps=1, tol=1e-9, part=0, project=True):
+def check_steps_against_oracle(ctx, case, dts, newton=True, n_steps=1, tol=1e-9, part=0, project=True, n_inner=1,
+                               step_kw=None):
     """Fused leapfrog steps against the C oracle chain by chain, starting from chain 0's on-manifold state with
     independent momenta (project=False: momenta that are NOT in the cotangent space, which the first half-kick of
     the integrator has to project -- the library then cannot use its projected-gradient shortcut)."""
@@ -120,12 +121,15 @@ def check_steps_against_oracle(ctx, case, dts, newton=True, n_steps=1, tol=1e-9,
         assert abs(h[c, 0] - chains[c].hamiltonian()) <= 1e-10 * max(1.0, abs(h[c, 0]))
     out = []
     dts = np.broadcast_to(np.asarray(dts, dtype=np.float64), (B,))
+    step_kw = step_kw or {}
+    okw = {{"max_iters": "max_iters", "reverse_check_tol": "rev_tol", "constraint_tol": "ctol", "position_tol": "ptol",
+            "divergence_tol": "dtol"}[k]: v for k, v in step_kw.items()}
     for _ in range(n_steps):
-        res = ctx.leapfrog_step(dts, newton=newton)
+        res = ctx.leapfrog_step(dts, newton=newton, n_inner_step=n_inner, **step_kw)
         q1, p1, _, _ = ctx.get_state()
         h1 = ctx.hamiltonian()
         for c in range(B):
-            st, itf, itb, rev = chains[c].step(dts[c], newton=newton)
+            st, itf, itb, rev = chains[c].step(dts[c], newton=newton, n_inner=n_inner, **okw)
             qo, po, _, _ = chains[c].get()
             assert res["status"][c] == st, (c, res["status"][c], st)
             assert res["iters_fwd"][c] == itf and (st != 0 or res["iters_bwd"][c] == itb), (c, res, itf, itb)
@@ -266,3 +270,50 @@ def halves_vs_single_batch(case, monkeypatch, part=0, n_steps=2, newton=True, ma
             assert np.array_equal(ra[k], rb[k]), k
     assert (a[2][0]["status"][list(masked)] == -1).all() and (a[2][0]["status"][list(failing)] > 0).all()
     return a
+
+
+def check_late_inner_failure(ctx, case, dts, n_inner=2):
+    """A chain whose step fails in a LATER inner h2-flow step (n_inner_step > 1) has already moved to an intermediate
+    point: the library must hand back the step's start state with valid caches.  The failure is provoked with a
+    reverse_check_tol between the round-off distances of the first and of the last inner step (both measured with
+    the library itself, whose round-off differs from the oracle's in the last bits)."""
+    osys, B = case["osys"], case["B"]
+    rng = case["rng"]
+    qq = np.repeat(case["q"][:1], B, 0)
+    xx = np.repeat(case["x_obs"][:1], B, 0)
+    p_raw = rng.standard_normal((B, ctx.Q))
+    dts = np.broadcast_to(np.asarray(dts, dtype=np.float64), (B,))
+
+    def reset():
+        ctx.set_state(qq, p_raw, xx, 0)
+        ctx.project_onto_cotangent_space()
+        return ctx.get_state()[:2]
+
+    reset()
+    rd_first = ctx.leapfrog_step(dts / n_inner, reverse_check_tol=1.0)["rev_err"]
+    reset()
+    rd_last = ctx.leapfrog_step(dts, n_inner_step=n_inner, reverse_check_tol=1.0)["rev_err"]
+    ratio = rd_last / np.maximum(rd_first, 1e-300)
+    c_late = int(np.argmax(ratio))
+    if not ratio[c_late] > 1.5:
+        return None  # no chain with a clearly larger round-off in the last inner step: the caller tries another case
+    tol = float(np.sqrt(rd_first[c_late] * rd_last[c_late]))  # inner step 1 passes, the last one fails for c_late
+    q0, p0 = reset()
+    res = ctx.leapfrog_step(dts, n_inner_step=n_inner, reverse_check_tol=tol)
+    q1, p1, _, _ = ctx.get_state()
+    assert res["status"][c_late] == 3 and rd_first[c_late] <= tol < res["rev_err"][c_late]
+    failed = res["status"] > 0
+    assert np.array_equal(q1[failed], q0[failed]) and np.array_equal(p1[failed], p0[failed])
+    # every chain (moved or restored) has valid caches: the next ordinary step agrees with an oracle chain started from
+    # the state the library reports
+    res = ctx.leapfrog_step(dts, n_inner_step=n_inner)
+    q2, p2, _, _ = ctx.get_state()
+    for c in range(B):
+        ch = c_oracle.OracleChain(osys)
+        ch.set(q1[c], p1[c], xx[c], 0)
+        st, itf, itb, _ = ch.step(dts[c], n_inner=n_inner)
+        qo, po, _, _ = ch.get()
+        assert res["status"][c] == st == 0 and res["iters_fwd"][c] == itf and res["iters_bwd"][c] == itb
+        assert np.abs(q2[c] - qo).max() <= 1e-9 * max(1.0, np.abs(qo).max())
+        assert np.abs(p2[c] - po).max() <= 1e-8 * max(1.0, np.abs(po).max())
+    return c_late

@@ -97,7 +97,7 @@ def test_api_misuse_is_reported(emu_lib):
         ctx.set_state(case["q"], None, case["x_obs"], 5)
     with pytest.raises(RuntimeError, match="n_inner_step"):
         ctx.set_state(case["q"], None, case["x_obs"], 0)
-        ctx.leapfrog_step(0.1, n_inner_step=2)
+        ctx.leapfrog_step(0.1, n_inner_step=0)
     ctx.close()
 
 
@@ -228,3 +228,30 @@ def test_half_batches_equal_one_batch(emu_lib, monkeypatch, model, T, S, R, nois
     case = make_case(model, T, S, R, noisy, B=7, seed=81, gaussian=gaussian)
     for part in range(2):
         halves_vs_single_batch(case, monkeypatch, part=part, newton=newton, masked=(1, 6), failing=(2, 4))
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy,gaussian,newton,n_inner", [
+    ("fhn", 6, 4, 2, True, False, True, 2), ("fhn", 7, 5, 3, False, True, True, 3), ("fhn", 12, 10, 5, True, False, False, 2),
+    ("sir", 6, 8, 2, True, False, True, 2)])
+def test_inner_h2_flow_steps(emu_lib, model, T, S, R, noisy, gaussian, newton, n_inner):
+    """n_inner_step > 1 on the fused path (mici _step_b loop; scripts/utils.py:131-136 --num-inner-h2-step) against the
+    C oracle, including a chain that fails in a LATER inner step and must get its start state back."""
+    case = make_case(model, T, S, R, noisy, B=4, seed=91, gaussian=gaussian)
+    ctx = make_ctx(case)
+    check_steps_against_oracle(ctx, case, np.array([0.06, -0.06, 0.1, 0.03]), newton=newton, n_steps=2, n_inner=n_inner)
+    check_steps_against_oracle(ctx, case, np.array([0.06, -0.06, 0.1, 0.03]), newton=newton, n_steps=1, n_inner=n_inner,
+                               project=False)
+    ctx.close()
+
+
+def test_failure_in_a_later_inner_step_restores_the_start_state(emu_lib):
+    from helpers import check_late_inner_failure
+    found = 0
+    for seed in range(93, 101):  # (which chain has the larger round-off in its last inner step depends on the arithmetic)
+        case = make_case("fhn", 12, 10, 5, True, B=6, seed=seed)
+        ctx = make_ctx(case)
+        found += check_late_inner_failure(ctx, case, np.array([0.08, -0.08, 0.1, 0.05, -0.1, 0.07])) is not None
+        ctx.close()
+        if found >= 2:
+            break
+    assert found >= 1

@@ -495,3 +495,51 @@ def test_half_batches_full_size(monkeypatch):
     from helpers import halves_vs_single_batch
     case = make_case("fhn", 100, 400, 5, True, B=130, seed=82)
     halves_vs_single_batch(case, monkeypatch, part=1, n_steps=2, masked=(0, 64, 65, 129), failing=(7, 100))
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy,gaussian,newton,n_inner", [
+    ("fhn", 12, 16, 5, True, False, True, 2), ("fhn", 7, 8, 3, False, True, True, 3), ("fhn", 12, 10, 5, True, False, False, 2),
+    ("sir", 14, 8, 14, True, False, True, 2), ("sir", 6, 16, 2, True, False, True, 2), ("fhn_nb", 7, 8, 3, False, True, True, 2)])
+def test_inner_h2_flow_steps(model, T, S, R, noisy, gaussian, newton, n_inner):
+    """n_inner_step > 1 on the fused device path (mici _step_b; scripts/utils.py:131-136 --num-inner-h2-step)."""
+    case = make_case(model, T, S, R, noisy, B=5, seed=91, gaussian=gaussian)
+    ctx = make_ctx(case)
+    dts = np.array([0.06, -0.06, 0.1, 0.03, -0.08])
+    for part in range(ctx.num_partition):
+        check_steps_against_oracle(ctx, case, dts, newton=newton, n_steps=2, n_inner=n_inner, part=part)
+    check_steps_against_oracle(ctx, case, dts, newton=newton, n_steps=1, n_inner=n_inner, project=False)
+    ctx.close()
+
+
+def test_failure_in_a_later_inner_step_restores_the_start_state():
+    from helpers import check_late_inner_failure
+    found = 0
+    for seed in range(93, 101):  # (which chain has the larger round-off in its last inner step depends on the arithmetic)
+        case = make_case("fhn", 12, 16, 5, True, B=6, seed=seed)
+        ctx = make_ctx(case)
+        found += check_late_inner_failure(ctx, case, np.array([0.08, -0.08, 0.1, 0.05, -0.1, 0.07])) is not None
+        ctx.close()
+        if found >= 2:
+            break
+    assert found >= 1
+
+
+def test_inner_steps_with_half_batches(monkeypatch):
+    """n_inner_step = 2 with the step run as two half-batches: bitwise equal to the one-batch run."""
+    case = make_case("fhn", 12, 16, 5, True, B=9, seed=94)
+    out = []
+    for halves in ("1", "2"):
+        monkeypatch.setenv("CHMC_HALVES", halves)
+        ctx = make_ctx(case)
+        ctx.set_state(np.repeat(case["q"][:1], 9, 0), np.random.default_rng(3).standard_normal((9, ctx.Q)),
+                      np.repeat(case["x_obs"][:1], 9, 0), 0)
+        dts = np.linspace(-0.1, 0.1, 9)
+        dts[4] = 5.0
+        r = [ctx.leapfrog_step(dts, n_inner_step=2, max_iters=12) for _ in range(2)]
+        out.append((ctx.get_state()[:2], r))
+        ctx.close()
+    (s1, r1), (s2, r2) = out
+    assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[1], s2[1])
+    for a, b in zip(r1, r2):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k

@@ -80,9 +80,16 @@ def test_composed_path_equals_fused_path(emu_lib):  # noqa: F811
     a, b = fused.step(st), composed.step(st)
     np.testing.assert_allclose(a.pos, b.pos, rtol=0, atol=1e-11)
     np.testing.assert_allclose(a.mom, b.mom, rtol=0, atol=1e-10)
+    # n_inner_step = 2: fused on the device against the host composition of the same inner steps
     two = mm.ConstrainedLeapfrogIntegrator(sysm, step_size=0.05, n_inner_step=2, projection_solver_kwargs=TOLS)
-    c = two.step(st)
+    two_composed = mm.ConstrainedLeapfrogIntegrator(
+        sysm, step_size=0.05, n_inner_step=2, projection_solver_kwargs=TOLS,
+        projection_solver=lambda *a, **k: mm.jitted_solve_projection_onto_manifold_newton(*a, **k))
+    assert two._fusable() and not two_composed._fusable()
+    c, d = two.step(st), two_composed.step(st)
     assert np.abs(sysm.constr(c)).max() < 1e-9
+    np.testing.assert_allclose(c.pos, d.pos, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(c.mom, d.mom, rtol=0, atol=1e-10)
 
 
 def test_errors_are_the_reference_exceptions(emu_lib):  # noqa: F811
