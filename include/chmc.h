@@ -37,18 +37,21 @@ extern "C" {
 typedef struct chmc_ctx chmc_ctx;
 
 /* Arguments of ConditionedDiffusionConstrainedSystem.__init__ (sde/mici_extensions.py:211-228) that can cross
- * a C ABI; the model callables are replaced by `model`.  Identity metric only. */
+ * a C ABI; the model callables are replaced by `model`.  The metric argument (identity, or block diagonal with a dense
+ * dim_u x dim_u first block, :279-315) is set with chmc_set_metric. */
 typedef struct chmc_config {
   int model;                  /* CHMC_MODEL_* */
   int num_obs;                /* T = y_seq.shape[0] (dim_y = 1) */
   int num_steps_per_obs;      /* S */
   int num_obs_per_subseq;     /* R; 0 or >= T: no partitioning (:321-324) */
-  int noisy;                  /* generate_sigma is not None (:353) */
+  int noisy;                  /* generate_sigma (:353-358): 0 None (noiseless observations), 1 a number (`sigma`),
+                               * 2 the model's generate_sigma_y(u) = exp(u[dim_z]) (fhn.py:46-47, sir.py:92-93):
+                               * variable observation noise, dim_u = dim_z + 1, q = [u(dim_u) | v_0 | v_seq | n] */
   int use_gaussian_splitting; /* :273-278 */
   int num_chains;             /* B */
   int device;                 /* HIP device ordinal */
   double obs_interval;
-  double sigma;               /* fixed observation-noise std (generate_sigma given as a Number, :354-358) */
+  double sigma;               /* fixed observation-noise std (generate_sigma given as a Number, :354-358); noisy == 1 only */
   const double* y_seq;        /* [T] */
 } chmc_config;
 

@@ -23,9 +23,12 @@ class ChmcContext:
             model=MODEL_IDS[model] if isinstance(model, str) else int(model), num_obs=len(y),
             num_steps_per_obs=int(num_steps_per_obs),
             num_obs_per_subseq=0 if num_obs_per_subseq is None else int(num_obs_per_subseq),
-            noisy=int(sigma is not None), use_gaussian_splitting=int(bool(use_gaussian_splitting)),
+            # sigma: None (noiseless observations), a number (fixed noise), or "variable": the model's
+            # generate_σ_y(u) = exp(u[dim_z]) (sde/example_models/fhn.py:46-47, sir.py:92-93), dim_u = dim_z + 1
+            noisy=2 if isinstance(sigma, str) else int(sigma is not None),
+            use_gaussian_splitting=int(bool(use_gaussian_splitting)),
             num_chains=int(num_chains), device=int(device), obs_interval=float(obs_interval),
-            sigma=0.0 if sigma is None else float(sigma), y_seq=ptr(y))
+            sigma=0.0 if sigma is None or isinstance(sigma, str) else float(sigma), y_seq=ptr(y))
         h = C.c_void_p()
         check(L.chmc_create(C.byref(cfg), C.byref(h)), "chmc_create")
         self.h = h
@@ -37,6 +40,7 @@ class ChmcContext:
         self.K = [int(d[12]), int(d[13])][: self.num_partition]
         self.V, self.V0 = int(d[14]), int(d[15])
         self.noisy = sigma is not None
+        self.variable_sigma = isinstance(sigma, str)
         self.sigma = sigma
         self.partition = 0
         self.blocks = []

@@ -46,6 +46,7 @@ struct BlockDesc {
 
 struct Sys {
   int B, T, S, noisy, gaussian;
+  int varsig;  // observation noise sigma = generate_sigma(u) = exp(u[Z]) (fhn.py:46-47, sir.py:92-93): U = Z + 1
   int U, X, V, Z, V0;
   int Q, NV, K, C, Kmax, RM, TRJ, NCOL;  // NCOL = NV + (noisy ? T : 0)
   double dl, sigma;
@@ -66,6 +67,8 @@ CHMC_HD inline double metric_inv_u(const Sys& sy, const double* vu, int a) {
   for (int b = 0; b < sy.U; ++b) t += W[b] * vu[b];
   return t;
 }
+// generate_sigma(u) of a chain with position q: a number (:354-358) or exp(u[dim_z]) with variable observation noise
+CHMC_HD inline double sigma_at(const Sys& sy, const double* q) { return sy.varsig ? exp(q[sy.Z]) : sy.sigma; }
 CHMC_HD inline double metric_mul_u(const Sys& sy, const double* vu, int a) {
   if (!sy.m0) return vu[a];
   const double* Mr = sy.m0 + a * sy.U;
@@ -318,6 +321,7 @@ CHMC_HD inline void fwd_block_impl(const Sys& sy, const BlockDesc& bd, const Cha
   const double* n = q + sy.U + sy.NV;
   for (int i = 0; i < RM; ++i) cp[i] = 0.0;
   const int L = bd.nsteps, S = sy.S;
+  const double sig = sy.noisy ? sigma_at(sy, q) : 0.0;
   // loads run up to PF steps past the block's end (never consumed): every q-like buffer is allocated with
   // CHMC_Q_PAD doubles of slack so that the scan needs no per-element bounds branches
   double cur[PF * V], nxt[PF * V];
@@ -346,7 +350,7 @@ CHMC_HD inline void fwd_block_impl(const Sys& sy, const BlockDesc& bd, const Cha
       if (left == 0) {  // s0 + PF is the time of local observation j
         if (j < bd.ny) {
           double yv = M::obs(x);
-          if (sy.noisy) yv += sy.sigma * n[bd.obs0 + j];
+          if (sy.noisy) yv += sig * n[bd.obs0 + j];
           cp[j] = yv - sy.y[bd.obs0 + j];
         }
         ++j;
@@ -372,7 +376,7 @@ CHMC_HD inline void fwd_block_impl(const Sys& sy, const BlockDesc& bd, const Cha
           if (--cnt == 0) {  // s + 1 is the time of local observation j
             if (j < bd.ny) {
               double yv = M::obs(x);
-              if (sy.noisy) yv += sy.sigma * n[bd.obs0 + j];
+              if (sy.noisy) yv += sig * n[bd.obs0 + j];
               cp[j] = yv - sy.y[bd.obs0 + j];
             }
             ++j;
@@ -405,8 +409,8 @@ CHMC_HD inline void fwd_block(const Sys& sy, const BlockDesc& bd, const ChainCon
 template <class M, int RM, int MODE>
 CHMC_HD inline void rev_block(const Sys& sy, const BlockDesc& bd, const ChainConsts<M>& cc, const double* u,
                               const double* q, const double* traj, double* Jv_out, const double* Jr, double* JuL,
-                              double* D) {
-  constexpr int X = M::X, V = M::V, Z = M::Z;
+                              double* D, double sig_prev) {  // sig_prev: sigma at the previous point (MODE 1)
+  constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U;
   const int S = sy.S, L = bd.nsteps, NV = sy.NV;
   double Lam[RM * X], zbar[RM * Z];
   for (int i = 0; i < RM * X; ++i) Lam[i] = 0.0;
@@ -538,19 +542,23 @@ CHMC_HD inline void rev_block(const Sys& sy, const BlockDesc& bd, const ChainCon
     for (int i = 0; i < RM; ++i)
       for (int j = 0; j < i; ++j) D[j * RM + i] = D[i * RM + j];
   }
-  const double s2 = sy.sigma * sy.sigma;
+  const double sig = sy.noisy ? sigma_at(sy, q) : 0.0;
+  const double s2 = sig * (MODE == 0 ? sig : sig_prev);  // dc_dn_l * dc_dn_r (:772-791)
   for (int i = 0; i < RM; ++i) {
     if (sy.noisy && i < bd.ny) D[i * RM + i] += s2;  // dc/dn dc/dn^T (:772-791)
     if (i >= bd.nrows) D[i * RM + i] = 1.0;          // identity padding
   }
   double G[Z * Z];
   M::gz_jac(u, G);
-  for (int i = 0; i < RM; ++i)
+  for (int i = 0; i < RM; ++i) {
     for (int c = 0; c < Z; ++c) {
       double t = 0.0;
       for (int mz = 0; mz < Z; ++mz) t += zbar[i * Z + mz] * G[mz * Z + c];
-      JuL[i * Z + c] = t;
+      JuL[i * U + c] = t;
     }
+    // d(sigma(u) n_i) / du_sigma = sigma n_i on the observation rows (g_y_bar :559-569)
+    if (M::VS) JuL[i * U + Z] = i < bd.ny ? sig * q[sy.U + sy.NV + bd.obs0 + i] : 0.0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -699,7 +707,7 @@ struct KStateBlk {
   CHMC_HD void operator()(int tid) const {
     CHMC_CB_DECODE
     if (!w.ok[c]) return;
-    constexpr int U = M::Z;
+    constexpr int U = M::U;
     const int s = sl.cur[c] ^ which;
     const double* q = pick(sl.q, s) + (size_t)c * sy.Q;
     ChainConsts<M> cc;
@@ -710,7 +718,7 @@ struct KStateBlk {
     double* cout_ = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
     for (int i = 0; i < RM; ++i) cout_[i] = cp[i];
     double D[RM * RM], Ju[RM * U];
-    rev_block<M, RM, 0>(sy, bd, cc, q, q, traj, pick(sl.Jv, s) + (size_t)c * RM * sy.NV, nullptr, Ju, D);
+    rev_block<M, RM, 0>(sy, bd, cc, q, q, traj, pick(sl.Jv, s) + (size_t)c * RM * sy.NV, nullptr, Ju, D, 0.0);
     const size_t cb = (size_t)c * sy.Kmax + b;
     double ld = chol_lower<RM>(D);
     double* fd = pick(sl.facD, s) + cb * RM * RM;
@@ -743,7 +751,7 @@ struct KStateChain {
   int which;
   CHMC_HD void operator()(int c) const {
     if (!w.ok[c]) return;
-    constexpr int U = M::Z;
+    constexpr int U = M::U;
     const int s = sl.cur[c] ^ which;
     double Cm[U * U];
     for (int i = 0; i < U * U; ++i) Cm[i] = 0.0;
@@ -769,6 +777,27 @@ struct KStateChain {
   }
 };
 
+// Variable observation noise, sigma = generate_sigma(u) = exp(u_sigma): on the observation rows
+// c_i = obs_func(x) + sigma(u) n_i - y_i, so the Jacobian entries dc_i/du_sigma = sigma n_i and dc_i/dn_i = sigma depend
+// on (u_sigma, n_i).  With W = G^-1 J M^-1 (W[i, u_sigma] = Wu[i][Z], W[i, n_i] = (G^-1)_ii sigma) the gradient of
+// 1/2 log det G gains   d/du_sigma: sum_i sigma (Wu[i][Z] n_i + sigma (G^-1)_ii)   and   d/dn_i: sigma Wu[i][Z].
+// Writes the n-components of this block into g (the chain's gradient) and returns the block's u_sigma term.
+template <int RM>
+CHMC_HD inline double var_sigma_grad_terms(const Sys& sy, const BlockDesc& bd, const double* q, const double* Wu, int U,
+                                           const double* Mb, double* g) {
+  const double sg = sigma_at(sy, q);
+  const double* n = q + sy.U + sy.NV + bd.obs0;
+  double* gn = g + sy.U + sy.NV + bd.obs0;
+  double acc = 0.0;
+  for (int i = 0; i < RM; ++i)
+    if (i < bd.ny) {
+      const double wz = Wu[i * U + sy.Z];
+      acc += sg * (wz * n[i] + sg * Mb[i * RM + i]);
+      gn[i] = sg * wz;
+    }
+  return acc;
+}
+
 // Gradient of 1/2 log det Gram, block part (value_and_grad of log_det_sqrt_gram :812-820, :1143-1146):
 // grad = sum_i grad_q [ grad c_i . w_i ],  W = G^-1 J on J's block pattern, i.e. per block one tangent
 // sweep per row along w_i and one second-order adjoint sweep with the sources summed over rows.
@@ -781,7 +810,7 @@ struct KGldBlk {
   CHMC_HD void operator()(int tid) const {
     CHMC_CB_DECODE
     if (!w.ok[c]) return;
-    constexpr int X = M::X, V = M::V, Z = M::Z, U = M::Z, V0 = M::V0, NXI = M::NXI;
+    constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0, NXI = M::NXI;
     const int s = sl.cur[c] ^ which;
     const int S = sy.S, L = bd.nsteps, NV = sy.NV;
     const size_t cb = (size_t)c * sy.Kmax + b;
@@ -825,7 +854,7 @@ struct KGldBlk {
           for (int j = 0; j < RM; ++j) Mb[i * RM + j] = 0.0, Mb[j * RM + i] = 0.0;
         for (int mz = 0; mz < Z; ++mz) {
           double t = 0.0;
-          for (int d = 0; d < U; ++d) t += Gz[mz * Z + d] * Wu[i * U + d];
+          for (int d = 0; d < Z; ++d) t += Gz[mz * Z + d] * Wu[i * U + d];
           zd[i * Z + mz] = t;
         }
       }
@@ -1015,7 +1044,7 @@ struct KGldBlk {
         }
     }
     double gu[U];
-    for (int d = 0; d < U; ++d) {
+    for (int d = 0; d < Z; ++d) {
       double t = 0.0;
       for (int mz = 0; mz < Z; ++mz) t += Gz[mz * Z + d] * zbt[mz];
       gu[d] = t;
@@ -1023,8 +1052,9 @@ struct KGldBlk {
     for (int i = 0; i < RM; ++i) {
       double o[Z];
       M::gz_hess(q, Wu + i * U, zbar + i * Z, o);
-      for (int d = 0; d < U; ++d) gu[d] += o[d];
+      for (int d = 0; d < Z; ++d) gu[d] += o[d];
     }
+    if (M::VS) gu[Z] = var_sigma_grad_terms<RM>(sy, bd, q, Wu, U, Mb, pick(sl.grad, s) + (size_t)c * sy.Q);
     for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
   }
 };
@@ -1040,7 +1070,7 @@ struct KGldPrep {
   CHMC_HD void operator()(int tid) const {
     CHMC_CB_DECODE
     if (!w.ok[c]) return;
-    constexpr int Z = M::Z, U = M::Z;
+    constexpr int Z = M::Z, U = M::U;
     const int s = sl.cur[c] ^ which;
     const size_t cb = (size_t)c * sy.Kmax + b;
     const double* q = pick(sl.q, s) + (size_t)c * sy.Q;
@@ -1073,7 +1103,7 @@ struct KGldPrep {
       for (int d = 0; d < U; ++d) w.gWu[(cb * RM + i) * U + d] = Wu[i * U + d];
       for (int mz = 0; mz < Z; ++mz) {
         double t = 0.0;
-        for (int d = 0; d < U; ++d) t += Gz[mz * Z + d] * Wu[i * U + d];
+        for (int d = 0; d < Z; ++d) t += Gz[mz * Z + d] * Wu[i * U + d];
         w.gzd[(cb * RM + i) * Z + mz] = t;
       }
     }
@@ -1088,7 +1118,7 @@ struct KGldChain {
   int which;
   CHMC_HD void operator()(int c) const {
     if (!w.ok[c]) return;
-    constexpr int U = M::Z;
+    constexpr int U = M::U;
     const int s = sl.cur[c] ^ which;
     double* g = pick(sl.grad, s) + (size_t)c * sy.Q;
     for (int d = 0; d < U; ++d) {
@@ -1096,8 +1126,8 @@ struct KGldChain {
       for (int b = 0; b < sy.K; ++b) t += w.gup[((size_t)c * sy.Kmax + b) * U + d];
       g[d] = t;
     }
-    if (sy.noisy)  // fixed observation noise: the Gram matrix does not depend on n
-      for (int t = 0; t < sy.T; ++t) g[sy.U + sy.NV + t] = 0.0;
+    if (sy.noisy && !sy.varsig)  // fixed observation noise: the Gram matrix does not depend on n
+      for (int t = 0; t < sy.T; ++t) g[sy.U + sy.NV + t] = 0.0;  // (variable noise: written by var_sigma_grad_terms)
   }
 };
 
@@ -1113,7 +1143,7 @@ struct KNewtonBlk {
   CHMC_HD void operator()(int tid) const {
     CHMC_CB_DECODE
     if (!w.nw[c]) return;
-    constexpr int U = M::Z;
+    constexpr int U = M::U;
     const int sp = sl.cur[c] ^ prev;
     const double* q = (qsel ? w.qb : pick(sl.q, sp ^ 1)) + (size_t)c * sy.Q;
     ChainConsts<M> cc;
@@ -1125,7 +1155,8 @@ struct KNewtonBlk {
     double* cout_ = w.cpad + cb * RM;
     for (int i = 0; i < RM; ++i) cout_[i] = cp[i];
     double D[RM * RM], JuL[RM * U];
-    rev_block<M, RM, 1>(sy, bd, cc, q, q, traj, nullptr, pick(sl.Jv, sp) + (size_t)c * RM * sy.NV, JuL, D);
+    rev_block<M, RM, 1>(sy, bd, cc, q, q, traj, nullptr, pick(sl.Jv, sp) + (size_t)c * RM * sy.NV, JuL, D,
+                        sy.noisy ? sigma_at(sy, pick(sl.q, sp) + (size_t)c * sy.Q) : 0.0);
     int piv[RM];
     lu_factor<RM>(D, piv);
     lu_solve<RM, 1>(D, piv, cp);
@@ -1163,7 +1194,7 @@ struct KNewtonFactor {  // LU of D = Jv(q) Jv(q_prev)^T + diag, D^-1 c, D^-1 dc/
     CHMC_CB_DECODE
     if (!w.nw[c]) return;
     (void)bd;
-    constexpr int U = M::Z;
+    constexpr int U = M::U;
     const int sp = sl.cur[c] ^ prev;
     const size_t cb = (size_t)c * sy.Kmax + b;
     double D[RM * RM], JuL[RM * U], cp[RM];
@@ -1199,7 +1230,7 @@ struct KStateFactor {  // Cholesky of D = Jv Jv^T + diag, D^-1 dc/du, C_b, log d
     CHMC_CB_DECODE
     if (!w.ok[c]) return;
     (void)bd;
-    constexpr int U = M::Z;
+    constexpr int U = M::U;
     const int s = sl.cur[c] ^ which;
     const size_t cb = (size_t)c * sy.Kmax + b;
     double D[RM * RM], Ju[RM * U], E[RM * U];
@@ -1229,7 +1260,7 @@ struct KSymBlk {
   CHMC_HD void operator()(int tid) const {
     CHMC_CB_DECODE
     if (use_nw ? !w.nw[c] : !w.ok[c]) return;
-    constexpr int U = M::Z;
+    constexpr int U = M::U;
     const int s = sl.cur[c] ^ which;
     const size_t cb = (size_t)c * sy.Kmax + b;
     double Dl[RM * RM], t[RM];
@@ -1262,7 +1293,7 @@ struct KSolveChain {
   int which, qsel, psel;  // which: slot holding the (previous-point) factors and dc/du
   CHMC_HD void operator()(int c) const {
     if (TGT == 0 ? !w.nw[c] : !w.ok[c]) return;
-    constexpr int U = M::Z;
+    constexpr int U = M::U;
     const int s = sl.cur[c] ^ which;
     double sacc[U];
     for (int a = 0; a < U; ++a) sacc[a] = 0.0;
@@ -1372,14 +1403,14 @@ struct KUpdate {
     const int t = col - sy.NV;
     const int b = sy.obs2blk[t];
     const int j = t - sy.blk[b].obs0;
-    return j < sy.blk[b].ny ? sy.sigma * w.lampad2[((size_t)c * sy.Kmax + b) * RM + j] : 0.0;
+    return j < sy.blk[b].ny ? sigma_at(sy, pick(sl.q, sl.cur[c] ^ which) + (size_t)c * sy.Q) * w.lampad2[((size_t)c * sy.Kmax + b) * RM + j] : 0.0;
   }
   CHMC_HD unsigned long long* red(int c) const { return TGT == 0 ? &w.ndq[c] : nullptr; }
   CHMC_HD double ncol_part(int c, int col) const {  // observation-noise columns: dc/dn = sigma on y rows (:601-608)
     const int t = col - sy.NV;
     const int b = sy.obs2blk[t];
     const int j = t - sy.blk[b].obs0;
-    return j < sy.blk[b].ny ? sy.sigma * w.lampad[((size_t)c * sy.Kmax + b) * RM + j] : 0.0;
+    return j < sy.blk[b].ny ? sigma_at(sy, pick(sl.q, sl.cur[c] ^ which) + (size_t)c * sy.Q) * w.lampad[((size_t)c * sy.Kmax + b) * RM + j] : 0.0;
   }
   CHMC_HD unsigned long long operator()(int c, int idx) const {
     const int s = sl.cur[c] ^ which;
@@ -1620,7 +1651,7 @@ struct KJw {
       double a2 = 0.0;
       for (int k = 0; k < bd.ncols; ++k) a2 += Jv[k] * wv[k];
       acc += a2;
-      if (sy.noisy && i < bd.ny) acc += sy.sigma * vct[sy.U + sy.NV + bd.obs0 + i];
+      if (sy.noisy && i < bd.ny) acc += sigma_at(sy, pick(sl.q, s) + (size_t)c * sy.Q) * vct[sy.U + sy.NV + bd.obs0 + i];
     }
     w.cpad[cb * RM + i] = acc;
   }
@@ -1744,10 +1775,16 @@ struct KMomFixInitPg {
     po.x = pn.x - sc * (flow.x - qn.x), po.y = pn.y - sc * (flow.y - qn.y);
     go.x = gr.x + (sy.gaussian ? 0.0 : qn.x), go.y = gr.y + (sy.gaussian ? 0.0 : qn.y);
     if (sy.m0 && col < sy.U) {
-      // Block metric, u-part (U even, <= 8: chmc_set_metric): the multiplier term is mu_u = M_0 (flow - q_new)_u with
+      // Block metric, u-part (U <= 8: chmc_set_metric): the multiplier term is mu_u = M_0 (flow - q_new)_u with
       // flow_u = q_prev_u + dt (M_0^-1 p)_u.  Every u-component needs all of p_u, which is updated in place, so the
       // first work item of the row handles the whole u-part and the others leave it alone.
-      if (col != 0) return;
+      if (col != 0) {
+        if (col + 1 >= sy.U && two) {  // odd dim_u: the pair's second component is the first one outside the u-part
+          pick(sl.p, s)[i + 1] = po.y;
+          pick(sl.pg, s)[i + 1] = go.y;
+        }
+        return;
+      }
       const size_t cq = (size_t)c * sy.Q;
       const double* qpu = pick(sl.q, s ^ 1) + cq;
       const double* qnu = pick(sl.q, s) + cq;

@@ -11,6 +11,8 @@ namespace chmc {
 struct FhnModel {
   static constexpr int ID = 0, X = CHMC_FHN_X, V = CHMC_FHN_V, Z = CHMC_FHN_Z, V0 = CHMC_FHN_V0, NK = CHMC_FHN_NK;
   static constexpr int NXI = X + V + Z;
+  static constexpr int U = Z;        // dim_u: the global parameters (fixed observation noise)
+  static constexpr bool VS = false;  // variable observation noise
   CHMC_HD static void precompute(const double* z, double dl, double* k) { chmc_fhn_precompute(z, dl, k); }
   CHMC_HD static void step(const double* k, const double* x, const double* v, double* xn) { chmc_fhn_step(k, x, v, xn); }
   CHMC_HD static void jac(const double* k, const double* x, const double* v, double* A, double* B, double* Zf) {
@@ -37,6 +39,8 @@ struct FhnModel {
 struct FhnNbModel {
   static constexpr int ID = 2, X = CHMC_FHNNB_X, V = CHMC_FHNNB_V, Z = CHMC_FHNNB_Z, V0 = CHMC_FHNNB_V0, NK = CHMC_FHNNB_NK;
   static constexpr int NXI = X + V + Z;
+  static constexpr int U = Z;        // dim_u: the global parameters (fixed observation noise)
+  static constexpr bool VS = false;  // variable observation noise
   CHMC_HD static void precompute(const double* z, double dl, double* k) { chmc_fhnnb_precompute(z, dl, k); }
   CHMC_HD static void step(const double* k, const double* x, const double* v, double* xn) { chmc_fhnnb_step(k, x, v, xn); }
   CHMC_HD static void jac(const double* k, const double* x, const double* v, double* A, double* B, double* Zf) {
@@ -64,6 +68,8 @@ struct FhnNbModel {
 struct SirModel {
   static constexpr int ID = 1, X = CHMC_SIR_X, V = CHMC_SIR_V, Z = CHMC_SIR_Z, V0 = CHMC_SIR_V0, NK = CHMC_SIR_NK;
   static constexpr int NXI = X + V + Z;
+  static constexpr int U = Z;        // dim_u: the global parameters (fixed observation noise)
+  static constexpr bool VS = false;  // variable observation noise
   CHMC_HD static void precompute(const double* z, double dl, double* k) { chmc_sir_precompute(z, dl, k); }
   CHMC_HD static void clip(const double* x, double* xc, bool* fr) {
     for (int a = 0; a < 2; ++a) {
@@ -119,5 +125,16 @@ struct SirModel {
   CHMC_HD static void obs_grad(const double* x, double* g) { chmc_sir_obs_grad(x, g); }
   CHMC_HD static void obs_hess_vec(const double* x, const double* xd, double* o) { chmc_sir_obs_hess_vec(x, xd, o); }
 };
+
+// Variable observation noise: generate_sigma(u) = exp(u[dim_z]) (fhn.py:46-47, sir.py:92-93), one more global parameter.
+// Everything that depends on the state dimension only is inherited; the kernels size their dc/du arrays with U and add
+// the d(sigma n_i)/du_sigma column and the sigma-dependent Gram diagonal where VS is set.
+template <class Base>
+struct VarSigma : Base {
+  static constexpr int U = Base::Z + 1;
+  static constexpr bool VS = true;
+};
+using FhnVsModel = VarSigma<FhnModel>;
+using SirVsModel = VarSigma<SirModel>;
 
 }  // namespace chmc

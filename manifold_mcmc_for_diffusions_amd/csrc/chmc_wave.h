@@ -67,7 +67,7 @@ __device__ inline void matmul_xx(const double* a, const double* b, double* c) { 
 // the register file: with it the sweep ran out of scratch memory, 25x slower than the 8-row instantiations.
 template <class M, int RM, int MODE, bool GRAM = true>
 __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int which, int qsel) {
-  constexpr int X = M::X, V = M::V, Z = M::Z, U = M::Z, V0 = M::V0;
+  constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0;
   // the fully unrolled 16-row instantiation WITH the Gram accumulator is mis-compiled by ROCm 7.2 under heavy register
   // spilling (wrong dc/du) and keeps its row loops rolled; everything else is fully unrolled
   constexpr int URM = (RM <= 8 || !GRAM) ? 64 : 1;
@@ -355,7 +355,9 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
 #pragma unroll URM
           for (int jj = 0; jj < i; ++jj) Dacc[jj * RM + i] = Dacc[i * RM + jj];
       }
-      const double s2 = sy.sigma * sy.sigma;
+      // dc_dn_l * dc_dn_r (:772-791): sigma at the iterate times sigma at the point whose rows are stored
+      const double sg_ = sy.noisy ? sigma_at(sy, q) : 0.0;
+      const double s2 = sg_ * (MODE == 0 || !sy.noisy ? sg_ : sigma_at(sy, pick(sl.q, sl_) + (size_t)c * sy.Q));
 #pragma unroll URM
       for (int i = 0; i < RM; ++i) {
         if (sy.noisy && i < bd.ny) Dacc[i * RM + i] += s2;  // dc/dn dc/dn^T (:772-791)
@@ -373,12 +375,15 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
     double G[Z * Z];
     M::gz_jac(q, G);
     double* ju = (MODE == 0 ? pick(sl.JuP, sl_) : w.JuL) + cb * RM * U;
-    for (int i = 0; i < RM; ++i)
+    for (int i = 0; i < RM; ++i) {
       for (int d = 0; d < Z; ++d) {
         double tt = 0.0;
         for (int mz = 0; mz < Z; ++mz) tt += zacc[i * Z + mz] * G[mz * Z + d];
         ju[i * U + d] = tt;
       }
+      // d(sigma(u) n_i) / du_sigma = sigma n_i on the observation rows (g_y_bar :559-569)
+      if (M::VS) ju[i * U + Z] = i < bd.ny ? sigma_at(sy, q) * q[sy.U + sy.NV + bd.obs0 + i] : 0.0;
+    }
   }
 }
 
@@ -387,7 +392,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
 // Ja: rows of the iterate (work.JvW) or of the slot itself, Jb: stored rows of slot `which`.  One wavefront per
 // (chain, block, group of NRG rows): NRG x RM accumulators per lane, lanes stride over the block's columns.
 template <int RM, int NRG>
-__global__ void __launch_bounds__(256) k_gram_rows(Sys sy, Slots sl, Work w, int which, int newton) {
+__global__ void __launch_bounds__(256) k_gram_rows(Sys sy, Slots sl, Work w, int which, int newton, int qsel) {
   constexpr int NG = RM / NRG;
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -423,7 +428,9 @@ __global__ void __launch_bounds__(256) k_gram_rows(Sys sy, Slots sl, Work w, int
     acc[i] = v;
   }
   if (lane == 0) {
-    const double s2 = sy.sigma * sy.sigma;
+    // dc_dn_l * dc_dn_r: sigma at the point of the rows Ja (the Newton iterate, or the slot itself) times sigma of the slot
+    const double sgb = sy.noisy ? sigma_at(sy, pick(sl.q, s) + (size_t)c * sy.Q) : 0.0;
+    const double s2 = sgb * (newton && sy.noisy ? sigma_at(sy, (qsel ? w.qb : pick(sl.q, s ^ 1)) + (size_t)c * sy.Q) : sgb);
     double* Do = w.Dw + cb * RM * RM + (size_t)g * NRG * RM;
 #pragma unroll
     for (int i = 0; i < NRG; ++i) {
@@ -682,10 +689,11 @@ __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int w
     if (i < bd.nrows) {
       const double* ju = pick(sl.JuP, s) + (cb * RM + i) * sy.U;
       for (int d = 0; d < sy.U; ++d) a += ju[d] * (minv ? metric_inv_u(sy, vct, d) : vct[d]);
-      if (sy.noisy && i < bd.ny) a += sy.sigma * vct[sy.U + sy.NV + bd.obs0 + i];
+      const double sg = sy.noisy ? sigma_at(sy, pick(sl.q, s) + (size_t)c * sy.Q) : 0.0;
+      if (sy.noisy && i < bd.ny) a += sg * vct[sy.U + sy.NV + bd.obs0 + i];
       if (TWO) {
         for (int d = 0; d < sy.U; ++d) a2 += ju[d] * (minv ? metric_inv_u(sy, vct2, d) : vct2[d]);
-        if (sy.noisy && i < bd.ny) a2 += sy.sigma * vct2[sy.U + sy.NV + bd.obs0 + i];
+        if (sy.noisy && i < bd.ny) a2 += sg * vct2[sy.U + sy.NV + bd.obs0 + i];
       }
     } else {
       a = 0.0, a2 = 0.0;
@@ -897,7 +905,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
 
 template <class M, int RM>
 __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, int which) {
-  constexpr int X = M::X, V = M::V, Z = M::Z, U = M::Z, V0 = M::V0, NXI = M::NXI;
+  constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0, NXI = M::NXI;
   constexpr int URM = RM <= 8 ? 64 : 1;
   __shared__ double sm[4][RM * RM + RM * Z];
   const int lane = threadIdx.x & 63;
@@ -1154,7 +1162,7 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
   if (lane == 0) {
     double Gz[Z * Z], gu[U];
     M::gz_jac(q, Gz);
-    for (int d = 0; d < U; ++d) {
+    for (int d = 0; d < Z; ++d) {
       double tt = 0.0;
       for (int mz = 0; mz < Z; ++mz) tt += Gz[mz * Z + d] * zbt[mz];
       gu[d] = tt;
@@ -1164,8 +1172,11 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
       for (int d = 0; d < U; ++d) wu[d] = w.gWu[(cb * RM + i) * U + d];
       for (int mz = 0; mz < Z; ++mz) zb[mz] = w.zbP[(cb * RM + i) * Z + mz];
       M::gz_hess(q, wu, zb, o);
-      for (int d = 0; d < U; ++d) gu[d] += o[d];
+      for (int d = 0; d < Z; ++d) gu[d] += o[d];
     }
+    if (M::VS)  // variable observation noise: the sigma-dependent entries of J (see var_sigma_grad_terms)
+      gu[Z] = var_sigma_grad_terms<RM>(sy, bd, q, w.gWu + cb * RM * U, U, w.gMb + cb * RM * RM,
+                                       pick(sl.grad, s_) + (size_t)c * sy.Q);
     for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
   }
 }
@@ -1176,7 +1187,7 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
 // share of the u-columns of J^T lambda, which is reduced again.  Same template parameters as KSolveChain.
 template <class M, int RM, int SYM, int TGT>
 __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work w, int which, int qsel, int psel) {
-  constexpr int U = M::Z;
+  constexpr int U = M::U;
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (c >= sy.B) return;
@@ -1430,6 +1441,7 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
   const double* xobs = sy.xobs + (size_t)c * sy.T * X;
   ChainConsts<M> cc;
   cc.init(q, sy.dl);
+  const double sig = sy.noisy ? sigma_at(sy, q) : 0.0;
   double x[X], xn[X];
   const double* vb = q + sy.U;
   if (bd.first) {
@@ -1491,7 +1503,7 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
         left -= PF;
         if (left == 0) {  // st + PF is the time of local observation j
           if (st < L && j < bd.ny) {
-            const double val = (M::obs(x) + (sy.noisy ? sy.sigma * ov[2 * j + 1] : 0.0)) - ov[2 * j];
+            const double val = (M::obs(x) + (sy.noisy ? sig * ov[2 * j + 1] : 0.0)) - ov[2 * j];
 #pragma unroll
             for (int jj = 0; jj < RM; ++jj)
               if (jj == j) cp[jj] = val;

@@ -140,7 +140,15 @@ class _Sir:
         return np.exp(x_seq[..., 1:2])
 
 
+def _generate_sigma_y(u):
+    """generate_σ_y (sde/example_models/fhn.py:46-47, sir.py:92-93): observation-noise scale exp(u[4]) of a parameter
+    vector with dim_u = dim_z + 1 components."""
+    return np.exp(np.asarray(u)[..., 4])
+
+
 def _finish(cls):
+    if cls.name != "fhn_nb":  # (the notebook's model has noiseless observations)
+        cls.generate_σ_y = ModelHandle(cls, "generate_σ_y", _generate_sigma_y)
     cls.forward_func = ModelHandle(cls, "forward_func", cls._forward)
     cls.generate_z = ModelHandle(cls, "generate_z", cls._generate_z)
     cls.generate_x_0 = ModelHandle(cls, "generate_x_0", cls._generate_x_0)

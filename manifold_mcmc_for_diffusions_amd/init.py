@@ -28,10 +28,11 @@ def solve_for_v_seq(model, z, x_0, x_obs_seq, num_steps_per_obs, δ):
 
 
 def find_initial_state_by_linear_interpolation(model, obs_interval, num_steps_per_obs, y_seq, rng,
-                                               generate_x_obs_seq_init, noisy, u=None, v_0=None):
-    """Returns (q, x_obs_seq) for one chain; RNG draw order follows the reference (:1528-1532)."""
+                                               generate_x_obs_seq_init, noisy, u=None, v_0=None, dim_u=None):
+    """Returns (q, x_obs_seq) for one chain; RNG draw order follows the reference (:1528-1532).
+    dim_u: dim_z + 1 with variable observation noise (default dim_z)."""
     δ = obs_interval / num_steps_per_obs
-    u = rng.standard_normal(model.dim_z) if u is None else np.asarray(u, dtype=np.float64)
+    u = rng.standard_normal(model.dim_z if dim_u is None else dim_u) if u is None else np.asarray(u, dtype=np.float64)
     z = model.generate_z(u)
     v_0 = rng.standard_normal(model.dim_v_0) if v_0 is None else np.asarray(v_0, dtype=np.float64)
     x_0 = model.generate_x_0(z, v_0)
@@ -87,7 +88,8 @@ def find_initial_states_by_gradient_descent_noisy_system(ctx, rng, adam_step_siz
     at once (the SIR script's initialisation, scripts/sir_model_chmc_experiment.py:103-109).
 
     Adam descent on the negative log posterior density of the noisy-observation model in (u, v_0, v_seq),
-        1/2 sum_t r_t^2 + 1/2 |u_v|^2,   r_t = (y_t - obs_func(x_t(u_v))) / sigma          (fixed sigma: log sigma constant),
+        1/2 sum_t r_t^2 + T log sigma + 1/2 |u_v|^2,   r_t = (y_t - obs_func(x_t(u_v))) / sigma
+    (sigma fixed, or sigma = generate_σ_y(u) = exp(u[dim_z]) for a context with variable observation noise),
     until the mean squared residual drops below `threshold`; the point is then put on the manifold by setting the
     observation-noise components to the residuals (:1767-1775).  The residuals and their gradient come from the
     library: `ctx` must hold the whole observation sequence in ONE sub-sequence (num_obs_per_subseq >= num_obs, i.e.
@@ -98,14 +100,18 @@ def find_initial_states_by_gradient_descent_noisy_system(ctx, rng, adam_step_siz
         raise ValueError("needs a noisy-observation context with a single sub-sequence (num_obs_per_subseq >= num_obs)")
     B, Q, T = ctx.B, ctx.Q, ctx.T
     nuv = Q - T
-    sigma = float(ctx.sigma)
+    var_sigma = getattr(ctx, "variable_sigma", False)
+    iσ = ctx.U - 1                                         # index of log sigma in u (variable observation noise)
     xo0 = np.zeros((B, T, ctx.X))
 
     def residuals_and_grad(u_v):
         q = np.concatenate([u_v, np.zeros((B, T))], 1)
         ctx.set_state(q, None, xo0, 0)
-        c = ctx.constr()                                   # obs_func(x_t) - y_t
+        c = ctx.constr()                                   # obs_func(x_t) - y_t  (n = 0: independent of sigma)
+        sigma = np.exp(u_v[:, iσ:iσ + 1]) if var_sigma else float(ctx.sigma)
         g = ctx.rmult_by_jacob_constr(c / sigma ** 2)[:, :nuv] + u_v
+        if var_sigma:                                      # d/du_sigma [1/2 sum c^2 / sigma^2 + T log sigma]
+            g[:, iσ] += T - np.sum((c / sigma) ** 2, 1)
         return -c / sigma, g
 
     u_v = rng.standard_normal((B, nuv))

@@ -205,20 +205,25 @@ class ConditionedDiffusionConstrainedSystem:
         if use_gaussian_splitting and not _is_identity(metric):  # :293-300
             raise ValueError("Only identity matrix metric can be used with Gaussian splitting")
         m0 = _metric_m0(metric, dim_u)  # :305-315
-        if generate_σ is not None and not isinstance(generate_σ, Number):
-            raise NotImplementedError("Variable observation noise (callable generate_σ) is not implemented; pass the "
-                                      "fixed standard deviation as a number or None for noiseless observations.")
+        # generate_σ: None (noiseless), a number (:354-358), or the model's generate_σ_y handle: observation noise
+        # exp(u[dim_z]) with dim_u = dim_z + 1 (scripts/sir_model_chmc_experiment.py:44,58,77)
+        variable_σ = isinstance(generate_σ, ModelHandle)
+        if variable_σ and (generate_σ.model is not model or generate_σ.role != "generate_σ_y"):
+            raise TypeError("generate_σ must be a number, None, or the generate_σ_y handle of the same model")
+        if generate_σ is not None and not variable_σ and not isinstance(generate_σ, Number):
+            raise TypeError("generate_σ must be a number, None, or the model's generate_σ_y handle (callables cannot "
+                            "cross the C ABI: the device code of generate_σ_y = exp(u[dim_z]) is selected by the handle)")
         y_seq = np.asarray(y_seq, dtype=np.float64)
         if y_seq.ndim != 2 or y_seq.shape[1] != model.dim_y:
             raise ValueError(f"y_seq must have shape (num_obs, {model.dim_y})")
         dim_v_0 = dim_x if dim_v_0 is None else dim_v_0
-        if (dim_u, dim_x, dim_v, dim_v_0) != (model.dim_z, model.dim_x, model.dim_v, model.dim_v_0):
-            raise ValueError("dim_u / dim_x / dim_v / dim_v_0 do not match the model")
+        if (dim_u, dim_x, dim_v, dim_v_0) != (model.dim_z + int(variable_σ), model.dim_x, model.dim_v, model.dim_v_0):
+            raise ValueError("dim_u / dim_x / dim_v / dim_v_0 do not match the model (dim_u = dim_z + 1 with generate_σ_y)")
         self._metric = IdentityMatrix()
         self.use_gaussian_splitting = bool(use_gaussian_splitting)
         self.model = model
         self.ctx = ChmcContext(model.name, obs_interval, num_steps_per_obs, num_obs_per_subseq, y_seq[:, 0],
-                               sigma=None if generate_σ is None else float(generate_σ),
+                               sigma=None if generate_σ is None else "variable" if variable_σ else float(generate_σ),
                                use_gaussian_splitting=use_gaussian_splitting, num_chains=num_chains, device=device)
         self.num_chains = num_chains
         self.num_partition = self.ctx.num_partition  # :362
@@ -436,7 +441,7 @@ def find_initial_state_by_linear_interpolation(system, rng, generate_x_obs_seq_i
     from .init import find_initial_state_by_linear_interpolation as _find
     md = system.model_dict if not model_dict else model_dict
     q, x_obs_seq = _find(system.model, md["δ"] * md["num_steps_per_obs"], md["num_steps_per_obs"], md["y_seq"], rng,
-                         generate_x_obs_seq_init, md["generate_σ"] is not None, u=u, v_0=v_0)
+                         generate_x_obs_seq_init, md["generate_σ"] is not None, u=u, v_0=v_0, dim_u=md["dim_u"])
     state = ConditionedDiffusionHamiltonianState(pos=q, x_obs_seq=x_obs_seq)
     state.mom = system.sample_momentum(state, rng)
     return state

@@ -128,9 +128,11 @@ class OracleSystem:
         self.T, self.S = len(y), num_steps_per_obs
         self.R = 0 if num_obs_per_subseq is None else num_obs_per_subseq
         self.noisy = sigma is not None
-        self.h = L.orc_create(MODEL_IDS[model], self.T, self.S, self.R, int(self.noisy),
-                              0.0 if sigma is None else float(sigma), int(use_gaussian_splitting),
-                              float(obs_interval), _d(y))
+        # sigma: None (noiseless), a number, or "variable": generate_sigma(u) = exp(u[dim_z]), dim_u = dim_z + 1
+        self.variable_sigma = isinstance(sigma, str)
+        self.h = L.orc_create(MODEL_IDS[model], self.T, self.S, self.R, 2 if self.variable_sigma else int(self.noisy),
+                              0.0 if sigma is None or self.variable_sigma else float(sigma),
+                              int(use_gaussian_splitting), float(obs_interval), _d(y))
         if not self.h:
             raise ValueError("unsupported configuration")
         self.L = L
@@ -139,7 +141,7 @@ class OracleSystem:
         self.rmax = L.orc_rmax(self.h)
         self.NV = L.orc_dim_nv(self.h)
         self.X = {"fhn": 2, "sir": 3, "fhn_nb": 2}[model]
-        self.U = 4
+        self.U = 4 + int(self.variable_sigma)
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -713,8 +713,11 @@ def find_initial_state_by_linear_interpolation(system, rng, generate_x_obs_seq_i
 
 def make_system(model, obs_interval, num_steps_per_obs, num_obs_per_subseq, y_seq, sigma=None,
                 use_gaussian_splitting=False):
-    """Wiring of scripts/utils.py:254-270 for a model object of oracle.py.models."""
+    """Wiring of scripts/utils.py:254-270 for a model object of oracle.py.models.  sigma: None, a number, or "variable"
+    = the model's generate_σ_y with dim_u = dim_z + 1 (scripts/sir_model_chmc_experiment.py:44,58,77)."""
+    variable = isinstance(sigma, str)
     return ConditionedDiffusionConstrainedSystem(
-        obs_interval, num_steps_per_obs, num_obs_per_subseq, y_seq, model.dim_z, model.dim_x, model.dim_v,
-        model.forward_func, model.generate_x_0, model.generate_z, model.obs_func, generate_σ=sigma,
+        obs_interval, num_steps_per_obs, num_obs_per_subseq, y_seq, model.dim_z + int(variable), model.dim_x, model.dim_v,
+        model.forward_func, model.generate_x_0, model.generate_z, model.obs_func,
+        generate_σ=model.generate_sigma_y if variable else sigma,
         use_gaussian_splitting=use_gaussian_splitting, dim_v_0=model.dim_v_0)

@@ -29,6 +29,10 @@ CASES = [
     # the notebook's model (FitzHugh-Nagumo_example.ipynb): noiseless observations every 0.5, Gaussian splitting, R = 5
     ("fhn_nb_noiseless_gauss", "fhn_nb", 7, 25, 5, False, True, 0.5),
     ("fhn_nb_noisy_std", "fhn_nb", 6, 4, 2, True, False, 0.2),
+    # variable observation noise: sigma = generate_σ_y(u) = exp(u[4]), dim_u = 5 (scripts/sir_model_chmc_experiment.py:44-77)
+    ("sir_varsigma_single_block", "sir", 5, 6, None, "variable", False, 0.25),
+    ("sir_varsigma_partitioned", "sir", 6, 8, 2, "variable", False, 0.25),
+    ("fhn_varsigma_gauss", "fhn", 6, 4, 2, "variable", True, 0.2),
 ]
 TOLS = dict(constraint_tol=1e-9, position_tol=1e-8, max_iters=50)
 
@@ -69,14 +73,17 @@ def main():
             continue
         rng = np.random.default_rng(11 if mname == "sir" else sum(map(ord, name)))
         model = omodels.MODELS[mname]
-        sigma = (0.1 if mname in ("fhn", "fhn_nb") else 1.0) if noisy else None
-        q = random_q(mname, T, S, noisy, 1, rng)[0]
+        var_sigma = noisy == "variable"
+        noisy = bool(noisy)
+        sigma = "variable" if var_sigma else ((0.1 if mname in ("fhn", "fhn_nb") else 1.0) if noisy else None)
+        q = random_q(mname, T, S, noisy, 1, rng, var_sigma=var_sigma)[0]
         sys0 = osys.make_system(model, oi, S, R, np.zeros((T, 1)), sigma=sigma, use_gaussian_splitting=gaussian)
         xo = sys0._generate_x_obs_seq(osys.T(q)).numpy()
-        y = model.obs_func(osys.T(xo)).numpy() + (sigma * q[-T:, None] if noisy else 0.0)
+        sig0 = float(np.exp(q[model.dim_z])) if var_sigma else sigma
+        y = model.obs_func(osys.T(xo)).numpy() + (sig0 * q[-T:, None] if noisy else 0.0)
         sysm = osys.make_system(model, oi, S, R, y, sigma=sigma, use_gaussian_splitting=gaussian)
         out = dict(model=mname, T=T, S=S, R=-1 if R is None else R, noisy=noisy, gaussian=gaussian, obs_interval=oi,
-                   sigma=-1.0 if sigma is None else sigma, y=y[:, 0], q=q, x_obs=xo)
+                   sigma=-1.0 if sigma is None else (-2.0 if var_sigma else sigma), y=y[:, 0], q=q, x_obs=xo)  # -2: variable
         rmax = max(int(b.shape[-2]) for p in range(sysm.num_partition)
                    for b in sysm._jacob_constr_blocks(osys.T(q), osys.T(xo), p)[1])
         nv = model.dim_v_0 + T * S * model.dim_v

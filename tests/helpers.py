@@ -10,36 +10,44 @@ SIR_U = np.array([-1.0, -1.0, 1.0, 0.0])
 FHN_NB_U = np.array([-0.4, -0.0, 1.0, -0.4])  # notebook priors: sigma 0.30, eps 0.135, gamma 1.5, beta 0.8
 
 
-def random_q(model, T, S, noisy, B, rng, v_scale=0.3, u_scale=0.1):
+def random_q(model, T, S, noisy, B, rng, v_scale=0.3, u_scale=0.1, var_sigma=False):
+    """var_sigma: variable observation noise, u gets a fifth component log sigma (dim_u = dim_z + 1)."""
     m = em.MODELS[model]
-    Q = m.dim_z + m.dim_v_0 + T * S * m.dim_v + (T if noisy else 0)
+    U = m.dim_z + int(var_sigma)
+    Q = U + m.dim_v_0 + T * S * m.dim_v + (T if noisy else 0)
     q = np.zeros((B, Q))
     u0 = FHN_U if model == "fhn" else FHN_NB_U if model == "fhn_nb" else SIR_U
     q[:, :4] = u_scale * rng.standard_normal((B, 4)) + u0
+    if var_sigma:
+        q[:, 4] = (np.log(0.1) if model in ("fhn", "fhn_nb") else 0.0) + u_scale * rng.standard_normal(B)
     if model in ("fhn", "fhn_nb"):
-        q[:, 4:6] = 0.5 * rng.standard_normal((B, 2))
+        q[:, U:U + 2] = 0.5 * rng.standard_normal((B, 2))
     else:
-        q[:, 4:5] = 1.0 + 0.1 * rng.standard_normal((B, 1))
+        q[:, U:U + 1] = 1.0 + 0.1 * rng.standard_normal((B, 1))
     nv = T * S * m.dim_v
-    o = 4 + m.dim_v_0
+    o = U + m.dim_v_0
     q[:, o:o + nv] = v_scale * rng.standard_normal((B, nv))
     if noisy:
         q[:, o + nv:] = rng.standard_normal((B, T))
     return q
 
 
-def make_case(model, T, S, R, noisy, B, seed, obs_interval=None, gaussian=False):
+def make_case(model, T, S, R, noisy, B, seed, obs_interval=None, gaussian=False, var_sigma=False):
     """Random chain states; the data are generated from chain 0 so that chain 0 lies on the manifold
-    (c(q_0) = 0 in every partition).  Returns dict with q [B,Q], x_obs [B,T,X], y [T], sigma, oracle system."""
+    (c(q_0) = 0 in every partition).  Returns dict with q [B,Q], x_obs [B,T,X], y [T], sigma, oracle system.
+    var_sigma: sigma = generate_sigma(u) = exp(u[dim_z]) (noisy observations only); case["sigma"] is then "variable"."""
     rng = np.random.default_rng(seed)
     m = em.MODELS[model]
     if obs_interval is None:
         obs_interval = 0.2 if model in ("fhn", "fhn_nb") else 0.25
     sigma = (0.1 if model in ("fhn", "fhn_nb") else 1.0) if noisy else None
-    q = random_q(model, T, S, noisy, B, rng)
+    if var_sigma:
+        assert noisy
+        sigma = "variable"
+    q = random_q(model, T, S, noisy, B, rng, var_sigma=var_sigma)
     tmp = c_oracle.OracleSystem(model, obs_interval, S, R, np.zeros(T), sigma=sigma, use_gaussian_splitting=gaussian)
     xo = np.stack([tmp.generate_x_obs_seq(q[c]) for c in range(B)])
-    y = m.obs_func(xo[0])[:, 0] + (sigma * q[0, -T:] if noisy else 0.0)
+    y = m.obs_func(xo[0])[:, 0] + ((np.exp(q[0, m.dim_z]) if var_sigma else sigma) * q[0, -T:] if noisy else 0.0)
     osys = c_oracle.OracleSystem(model, obs_interval, S, R, y, sigma=sigma, use_gaussian_splitting=gaussian)
     return dict(model=model, T=T, S=S, R=R, noisy=noisy, B=B, q=q, x_obs=xo, y=y, sigma=sigma,
                 obs_interval=obs_interval, gaussian=gaussian, osys=osys, rng=rng)
@@ -151,7 +159,8 @@ def check_block_metric_against_oracle(ctx, case, newton, dts, n_steps=2, tol=1e-
     output, momentum sampling and fused leapfrog steps against the C oracle with the same M_0."""
     from test_rng import reference_normals
     osys, rng, B = case["osys"], case["rng"], case["B"]
-    M0 = random_metric(rng)
+    U = ctx.U
+    M0 = random_metric(rng, U)
     osys.set_metric(M0)
     try:
         ctx.set_metric(M0)
@@ -161,7 +170,7 @@ def check_block_metric_against_oracle(ctx, case, newton, dts, n_steps=2, tol=1e-
         qq, xx = np.repeat(q0[None], B, 0), np.repeat(x0[None], B, 0)
         ctx.set_state(qq, None, xx, 0)
         mv = 0.03 * rng.standard_normal((B, ctx.Q))
-        mv[:, :4] = mv[:, :4] @ np.linalg.inv(M0).T
+        mv[:, :U] = mv[:, :U] @ np.linalg.inv(M0).T
         dt = np.full(B, 0.05)
         r = ctx.project(qq + mv, dt, newton=newton)
         for c in range(B):
@@ -175,7 +184,7 @@ def check_block_metric_against_oracle(ctx, case, newton, dts, n_steps=2, tol=1e-
         Lc = np.linalg.cholesky(M0)
         for c in range(B):
             n = reference_normals(ctx.Q, c + 1, 77, 2)
-            n[:4] = Lc @ n[:4]
+            n[:U] = Lc @ n[:U]
             expect = n - osys.jacob_products(q0, x0, 0, n, np.zeros(ctx.dim_c))[3]
             np.testing.assert_allclose(p[c], expect, rtol=1e-9, atol=1e-10)
         # fused steps (tangent momenta: projected-kick shortcut; then from unprojected momenta)

@@ -255,3 +255,37 @@ def test_failure_in_a_later_inner_step_restores_the_start_state(emu_lib):
         if found >= 2:
             break
     assert found >= 1
+
+
+# variable observation noise: sigma = generate_σ_y(u) = exp(u[dim_z]), dim_u = dim_z + 1
+# (sde/mici_extensions.py:353-358, 559-569, 601-608; scripts/sir_model_chmc_experiment.py:44,58,77)
+VS_CASES = [("sir", 5, 6, None, False), ("sir", 6, 8, 2, False), ("fhn", 6, 4, 2, False), ("fhn", 7, 5, 3, True),
+            ("sir", 14, 6, 14, False)]
+
+
+@pytest.mark.parametrize("model,T,S,R,gaussian", VS_CASES)
+def test_variable_observation_noise(emu_lib, model, T, S, R, gaussian):
+    case = make_case(model, T, S, R, True, B=3, seed=11, gaussian=gaussian, var_sigma=True)
+    ctx = make_ctx(case)
+    assert ctx.U == 5 and ctx.Q == case["q"].shape[1]
+    check_ops_against_oracle(ctx, case)
+    ctx.close()
+    case = make_case(model, T, S, R, True, B=4, seed=12, gaussian=gaussian, var_sigma=True)
+    ctx = make_ctx(case)
+    dts = np.array([0.05, -0.05, 0.1, 0.02])
+    for newton in ((True,) if R == 14 else (True, False)):  # (14-row quasi-Newton counts sit on the tolerance's edge)
+        for part in range(ctx.num_partition):
+            check_steps_against_oracle(ctx, case, dts, newton=newton, n_steps=2, part=part)
+    check_steps_against_oracle(ctx, case, dts, n_steps=1, project=False)
+    check_steps_against_oracle(ctx, case, dts, n_steps=1, n_inner=2)
+    ctx.close()
+
+
+@pytest.mark.parametrize("model,T,S,R", [("sir", 6, 8, 2), ("fhn", 6, 4, 2)])
+def test_variable_observation_noise_block_metric(emu_lib, model, T, S, R):
+    """Odd dim_u = 5 with M = blockdiag(M_0, I)."""
+    from helpers import check_block_metric_against_oracle
+    case = make_case(model, T, S, R, True, B=4, seed=41, var_sigma=True)
+    ctx = make_ctx(case)
+    check_block_metric_against_oracle(ctx, case, True, np.array([0.05, -0.05, 0.08, 0.02]))
+    ctx.close()

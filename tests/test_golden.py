@@ -20,7 +20,8 @@ TOLS = dict(ctol=1e-9, ptol=1e-8, max_iters=50)
 def load(name):
     g = dict(np.load(os.path.join(HERE, "golden", name + ".npz")))
     cfg = dict(model=str(g["model"]), T=int(g["T"]), S=int(g["S"]), R=None if int(g["R"]) < 0 else int(g["R"]),
-               sigma=None if float(g["sigma"]) < 0 else float(g["sigma"]), gaussian=bool(g["gaussian"]),
+               sigma="variable" if float(g["sigma"]) == -2.0 else None if float(g["sigma"]) < 0 else float(g["sigma"]),
+               gaussian=bool(g["gaussian"]),
                obs_interval=float(g["obs_interval"]))
     return g, cfg
 

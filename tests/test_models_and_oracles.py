@@ -65,9 +65,15 @@ CASES = [("fhn", 6, 4, 2, True, False), ("fhn", 7, 5, 3, False, True), ("fhn", 9
          ("fhn_nb", 7, 5, 3, False, True), ("fhn_nb", 6, 4, 2, True, False)]
 
 
-@pytest.mark.parametrize("model,T,S,R,noisy,gaussian", CASES)
-def test_c_oracle_vs_autodiff_oracle(model, T, S, R, noisy, gaussian):
-    case = make_case(model, T, S, R, noisy, B=2, seed=21, gaussian=gaussian)
+# variable observation noise (generate_σ callable, dim_u = dim_z + 1: scripts/sir_model_chmc_experiment.py:44,58,77)
+VS_CASES = [("sir", 5, 6, None, True, False), ("sir", 6, 8, 2, True, False), ("fhn", 6, 4, 2, True, False),
+            ("fhn", 7, 5, 3, True, True)]
+
+
+@pytest.mark.parametrize("model,T,S,R,noisy,gaussian,var_sigma",
+                         [c + (False,) for c in CASES] + [c + (True,) for c in VS_CASES])
+def test_c_oracle_vs_autodiff_oracle(model, T, S, R, noisy, gaussian, var_sigma):
+    case = make_case(model, T, S, R, noisy, B=2, seed=21, gaussian=gaussian, var_sigma=var_sigma)
     osy = case["osys"]
     ref = osys.make_system(omodels.MODELS[model], case["obs_interval"], S, R, case["y"][:, None], sigma=case["sigma"],
                            use_gaussian_splitting=gaussian)
