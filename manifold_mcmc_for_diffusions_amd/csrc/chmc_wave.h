@@ -448,6 +448,73 @@ __global__ void __launch_bounds__(256) k_gram_rows(Sys sy, Slots sl, Work w, int
   }
 }
 
+// The same Gram block on the matrix cores: D (16 x 16) = Ja Jb^T as a chain of v_mfma_f64_16x16x4_f64, ONE wavefront
+// per (chain, block).  This is the dense J J^T contraction of compute_D_blocks (:765-792) that BASELINE.json's config 5
+// names; it only fits the hardware tile where a block has 16 row slots (the stored-rows path of the SIR single-block
+// layout) -- the 7-row FitzHugh-Nagumo blocks form their Gram in registers with the time index across the lanes, the
+// transpose of what the instruction wants.
+//   operand layout (cdna_hip_programming.md section 3): lane l, r = l & 15, g = l >> 4 supplies A[i = r][k = g] and
+//   B[k = g][j = r]; result register m holds D[row = g + 4 m][col = r].
+// Columns are read the coalesced way (lane = column, 512 contiguous bytes per row and instruction, next tile's loads in
+// flight during the current tile's MFMAs), parked in LDS (row stride 66 doubles: conflict-free ds_read_b64 of a [r][4 m + g]
+// pattern) and read back in operand layout: 16 MFMAs per tile of 64 columns.
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+template <int RM>
+__global__ void __launch_bounds__(64) k_gram_rows_mfma(Sys sy, Slots sl, Work w, int which, int newton, int qsel) {
+  static_assert(RM == 16, "the MFMA Gram kernel is the 16 x 16 x 4 fp64 tile");
+  constexpr int LDT = 66;
+  __shared__ double ta[RM * LDT], tb[RM * LDT];
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x;
+  if (wid >= sy.B * sy.K) return;
+  const int cbi = sy.order[wid];
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (newton ? !w.nw[c] : !w.ok[c]) return;
+  const BlockDesc bd = sy.blk[b];
+  const int s = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const double* Jb = pick(sl.Jv, s) + (size_t)c * RM * sy.NV + bd.col0;
+  const double* Ja = (newton ? w.JvW : pick(sl.Jv, s)) + (size_t)c * RM * sy.NV + bd.col0;
+  const int r = lane & 15, g = lane >> 4;
+  v4d_t acc = {0.0, 0.0, 0.0, 0.0};
+  double ra[RM], rb[RM];
+  auto fetch = [&](int k0) {
+    const int k = k0 + lane;
+    const bool in = k < bd.ncols;
+#pragma unroll
+    for (int i = 0; i < RM; ++i) {
+      ra[i] = in ? Ja[(size_t)i * sy.NV + k] : 0.0;
+      rb[i] = in ? Jb[(size_t)i * sy.NV + k] : 0.0;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < bd.ncols; k0 += 64) {
+#pragma unroll
+    for (int i = 0; i < RM; ++i) ta[i * LDT + lane] = ra[i], tb[i * LDT + lane] = rb[i];
+    if (k0 + 64 < bd.ncols) fetch(k0 + 64);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int m = 0; m < 16; ++m)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[r * LDT + 4 * m + g], tb[r * LDT + 4 * m + g], acc, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+  const double sgb = sy.noisy ? sigma_at(sy, pick(sl.q, s) + (size_t)c * sy.Q) : 0.0;
+  const double s2 = sgb * (newton && sy.noisy ? sigma_at(sy, (qsel ? w.qb : pick(sl.q, s ^ 1)) + (size_t)c * sy.Q) : sgb);
+  double* Do = w.Dw + cb * RM * RM;
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int gi = g + 4 * m, j = r;  // row of Ja, row of Jb
+    double v = acc[m];
+    if (gi == j) {
+      if (sy.noisy && gi < bd.ny) v += s2;
+      if (gi >= bd.nrows) v = 1.0;
+    }
+    Do[gi * RM + j] = v;
+  }
+}
+
 // Backward half of conditioned_diffusion_neg_log_dens_and_grad (:82-205): value and gradient of
 //   1/2 sum_t ((y_t - obs_func(x_t)) / sigma)^2 + T log sigma [+ 1/2 q^T q]        (fixed sigma, Y = 1)
 // by ONE adjoint sweep over the whole trajectory of a chain: one wavefront per chain, 64 consecutive steps per tile as
