@@ -128,6 +128,32 @@ static void stagger_record() {
   note(hipEventRecord(g_stag_ev[h][g_stag_n[h] % kStagRing], g_stream));
   g_stag_n[h]++;
 }
+// ---- side stream of the Newton loop (deferred sequential scans of the time-parallel forward scan): the work enqueued
+// between side_begin() and side_end() runs on the second half-batch stream behind everything the main stream has queued
+// so far; side_wait() makes the main stream wait for the latest such piece
+static thread_local hipEvent_t g_side_ev[2] = {nullptr, nullptr};
+static thread_local bool g_side_pending = false;
+static thread_local hipStream_t g_side_saved = nullptr;
+static void side_begin() {
+  if (!g_side_ev[0]) {
+    note(hipEventCreateWithFlags(&g_side_ev[0], hipEventDisableTiming));
+    note(hipEventCreateWithFlags(&g_side_ev[1], hipEventDisableTiming));
+  }
+  note(hipEventRecord(g_side_ev[0], g_stream));
+  note(hipStreamWaitEvent(g_streams[2], g_side_ev[0], 0));
+  g_side_saved = g_stream;
+  g_stream = g_streams[2];
+}
+static void side_end() {
+  note(hipEventRecord(g_side_ev[1], g_stream));
+  g_stream = g_side_saved;
+  g_side_pending = true;
+}
+static void side_wait() {
+  if (!g_side_pending) return;
+  note(hipStreamWaitEvent(g_stream, g_side_ev[1], 0));
+  g_side_pending = false;
+}
 static int dev_sync() {
   note(hipStreamSynchronize(g_stream));
   if (g_first_err != hipSuccess) {

@@ -126,11 +126,13 @@ struct Work {
   double* dt;       // [B]
   double* part;     // [B][NPART] partial sums
   int* iters;       // [B]
-  int* nw;          // [B] Newton loop active
+  int* nw;          // [B] Newton loop: 0 finished, 1 iterating, 2 / 3 forward scan of the current iterate handed to the
+                    //     side stream (pending / done): the chain sits this round of the loop out (k_fwd_par, K = 1)
   int* ok;          // [B] chain still good in this step
   int* status;      // [B]
   int* nstat;       // [B] status of last projection
   int* n_active;    // [1]
+  int* nfallback;   // [1] blocks the time-parallel forward scan handed to its sequential fallback (diagnostic)
 };
 
 // slot selection as an explicit select: indexing the by-value kernel-argument pointer pairs with a run-time slot
@@ -577,7 +579,7 @@ struct KFwd {
   int which, qsel, use_nw, store_traj;
   CHMC_HD void operator()(int tid) const {
     CHMC_CB_DECODE
-    if (use_nw ? !w.nw[c] : !w.ok[c]) return;
+    if (use_nw ? w.nw[c] != use_nw : !w.ok[c]) return;  // (use_nw 2: the deferred scans of the side stream)
     const int s = sl.cur[c] ^ which;
     const double* q = (qsel ? w.qb : pick(sl.q, s)) + (size_t)c * sy.Q;
     ChainConsts<M> cc;
@@ -589,6 +591,7 @@ struct KFwd {
     fwd_block<M, RM>(sy, bd, cc, q, sy.xobs + (size_t)c * sy.T * M::X, traj, cp);
     double* out = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
     for (int i = 0; i < RM; ++i) out[i] = cp[i];
+    if (use_nw == 2) w.nw[c] = 3;  // deferred scan done: the chain re-joins the loop in the next round (K = 1)
   }
 };
 
@@ -1054,7 +1057,7 @@ struct KGldBlk {
       M::gz_hess(q, Wu + i * U, zbar + i * Z, o);
       for (int d = 0; d < Z; ++d) gu[d] += o[d];
     }
-    if (M::VS) gu[Z] = var_sigma_grad_terms<RM>(sy, bd, q, Wu, U, Mb, pick(sl.grad, s) + (size_t)c * sy.Q);
+    if constexpr (M::VS) gu[Z] = var_sigma_grad_terms<RM>(sy, bd, q, Wu, U, Mb, pick(sl.grad, s) + (size_t)c * sy.Q);
     for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
   }
 };
@@ -1192,7 +1195,7 @@ struct KNewtonFactor {  // LU of D = Jv(q) Jv(q_prev)^T + diag, D^-1 c, D^-1 dc/
   int prev;
   CHMC_HD void operator()(int tid) const {
     CHMC_CB_DECODE
-    if (!w.nw[c]) return;
+    if (w.nw[c] != 1) return;
     (void)bd;
     constexpr int U = M::U;
     const int sp = sl.cur[c] ^ prev;
@@ -1259,7 +1262,7 @@ struct KSymBlk {
   int which, use_nw;
   CHMC_HD void operator()(int tid) const {
     CHMC_CB_DECODE
-    if (use_nw ? !w.nw[c] : !w.ok[c]) return;
+    if (use_nw ? w.nw[c] != 1 : !w.ok[c]) return;
     constexpr int U = M::U;
     const int s = sl.cur[c] ^ which;
     const size_t cb = (size_t)c * sy.Kmax + b;
@@ -1292,7 +1295,7 @@ struct KSolveChain {
   Work w;
   int which, qsel, psel;  // which: slot holding the (previous-point) factors and dc/du
   CHMC_HD void operator()(int c) const {
-    if (TGT == 0 ? !w.nw[c] : !w.ok[c]) return;
+    if (TGT == 0 ? w.nw[c] != 1 : !w.ok[c]) return;
     constexpr int U = M::U;
     const int s = sl.cur[c] ^ which;
     double sacc[U];
@@ -1398,7 +1401,7 @@ struct KUpdate {
   Slots sl;
   Work w;
   int which, qsel, psel;
-  CHMC_HD bool active(int c) const { return TGT == 0 ? w.nw[c] != 0 : w.ok[c] != 0; }
+  CHMC_HD bool active(int c) const { return TGT == 0 ? w.nw[c] == 1 : w.ok[c] != 0; }
   CHMC_HD double ncol_part2(int c, int col) const {  // same with the first vector's multipliers (TGT 3)
     const int t = col - sy.NV;
     const int b = sy.obs2blk[t];
@@ -1595,6 +1598,10 @@ struct KCheck {
   int max_iters, B;
   CHMC_HD void operator()(int c) const {
     if (!w.nw[c]) return;
+    if (w.nw[c] != 1) {  // its forward scan is still with the side stream: not this round's iteration, but not finished
+      atomic_add_i32(w.n_active, 1);
+      return;
+    }
     const int i = ++w.iters[c];
     const double err = w.err[c], ndq = bitsd(w.ndq[c]);
     const bool diverged = (err > dtol) || (err != err);

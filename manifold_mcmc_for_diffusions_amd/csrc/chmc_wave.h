@@ -68,16 +68,17 @@ __device__ inline void matmul_xx(const double* a, const double* b, double* c) { 
 template <class M, int RM, int MODE, bool GRAM = true>
 __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int which, int qsel) {
   constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0;
-  // the fully unrolled 16-row instantiation WITH the Gram accumulator is mis-compiled by ROCm 7.2 under heavy register
-  // spilling (wrong dc/du) and keeps its row loops rolled; everything else is fully unrolled
-  constexpr int URM = (RM <= 8 || !GRAM) ? 64 : 1;
+  // A 16 x 16 Gram accumulator per lane does not fit the register file (the sweep lived in scratch memory and its
+  // fully unrolled form produced wrong dc/du): 16-row blocks store their rows and k_gram_rows forms the Gram block.
+  static_assert(RM <= 8 || !GRAM, "16-row blocks: instantiate with GRAM = false and form the Gram block with k_gram_rows");
+  constexpr int URM = 64;
   constexpr bool STORE_ROWS = MODE == 0 || !GRAM;
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];  // work order: longest blocks first
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (MODE == 1 ? !w.nw[c] : !w.ok[c]) return;
+  if (MODE == 1 ? w.nw[c] != 1 : !w.ok[c]) return;
   const BlockDesc bd = sy.blk[b];
   const int sl_ = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
@@ -400,7 +401,7 @@ __global__ void __launch_bounds__(256) k_gram_rows(Sys sy, Slots sl, Work w, int
   const int g = wid % NG;
   const int cbi = sy.order[wid / NG];
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (newton ? !w.nw[c] : !w.ok[c]) return;
+  if (newton ? w.nw[c] != 1 : !w.ok[c]) return;
   const BlockDesc bd = sy.blk[b];
   const int s = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
@@ -469,7 +470,7 @@ __global__ void __launch_bounds__(64) k_gram_rows_mfma(Sys sy, Slots sl, Work w,
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (newton ? !w.nw[c] : !w.ok[c]) return;
+  if (newton ? w.nw[c] != 1 : !w.ok[c]) return;
   const BlockDesc bd = sy.blk[b];
   const int s = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
@@ -973,7 +974,11 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
 template <class M, int RM>
 __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, int which) {
   constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0, NXI = M::NXI;
+#ifdef CHMC_GLD_BWD_URM16
+  constexpr int URM = RM <= 8 ? 64 : CHMC_GLD_BWD_URM16;  // (experiments on the 16-row instantiation)
+#else
   constexpr int URM = RM <= 8 ? 64 : 1;
+#endif
   __shared__ double sm[4][RM * RM + RM * Z];
   const int lane = threadIdx.x & 63;
   const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1241,7 +1246,7 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
       M::gz_hess(q, wu, zb, o);
       for (int d = 0; d < Z; ++d) gu[d] += o[d];
     }
-    if (M::VS)  // variable observation noise: the sigma-dependent entries of J (see var_sigma_grad_terms)
+    if constexpr (M::VS)  // variable observation noise: the sigma-dependent entries of J (see var_sigma_grad_terms)
       gu[Z] = var_sigma_grad_terms<RM>(sy, bd, q, w.gWu + cb * RM * U, U, w.gMb + cb * RM * RM,
                                        pick(sl.grad, s_) + (size_t)c * sy.Q);
     for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
@@ -1258,7 +1263,7 @@ __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (c >= sy.B) return;
-  if (TGT == 0 ? !w.nw[c] : !w.ok[c]) return;
+  if (TGT == 0 ? w.nw[c] != 1 : !w.ok[c]) return;
   const int s = sl.cur[c] ^ which;
   const bool has = lane < sy.K;
   const size_t cb = (size_t)c * sy.Kmax + (has ? lane : 0);
@@ -1439,7 +1444,7 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
     int L = 0;
     if (t < n) {
       const int c = t / sy.K;
-      if (use_nw ? w.nw[c] != 0 : w.ok[c] != 0) L = sy.blk[t - c * sy.K].nsteps;
+      if (use_nw ? w.nw[c] == 1 : w.ok[c] != 0) L = sy.blk[t - c * sy.K].nsteps;
     }
     maxL = L;
 #pragma unroll
@@ -1462,7 +1467,7 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
       rp[i] = w.trajw, rL[i] = 0, lo_[i] = r * RSD + 2 * ch;  // (a global pointer: no generic-address stores)
       if (t < n) {
         const int c = t / sy.K, b = t - c * sy.K;
-        if (use_nw ? w.nw[c] != 0 : w.ok[c] != 0) {
+        if (use_nw ? w.nw[c] == 1 : w.ok[c] != 0) {
           const BlockDesc bd = sy.blk[b];
           const int s = sl.cur[c] ^ which;
           rp[i] = (store_traj == 2 ? w.trajw : pick(sl.traj, s)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X + 2 * ch;
@@ -1501,7 +1506,7 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
   const int tc = tid < n ? tid : n - 1;  // lanes past the end shadow the last block (valid addresses, no output)
   const int c = tc / sy.K, b = tc - c * sy.K;
   const BlockDesc bd = sy.blk[b];
-  const bool act = tid < n && (use_nw ? w.nw[c] != 0 : w.ok[c] != 0);
+  const bool act = tid < n && (use_nw ? w.nw[c] == 1 : w.ok[c] != 0);
   const int L = act ? bd.nsteps : 0;
   const int s = sl.cur[c] ^ which;
   const double* q = (qsel ? w.qb : pick(sl.q, s)) + (size_t)c * sy.Q;
@@ -1602,6 +1607,213 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
   double* out = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
 #pragma unroll
   for (int i = 0; i < RM; ++i) out[i] = cp[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Time-parallel forward scan of `constr` for layouts with FEW, LONG blocks (the SIR single-block configuration: K = 1,
+// 2 800 steps -- a lane-per-block scan then keeps 4 wavefronts of the whole chip busy for 0.9 ms).  One wavefront per
+// (chain, block) integrates the block by MULTIPLE SHOOTING: the block is cut into 64 segments, lane l integrates
+// segment l with the exact nonlinear recursion from a guessed start state U_l (taken from a nearby trajectory: the
+// previous Newton iterate of the retraction, or the state's own trajectory) and accumulates the segment's transition
+// matrix A_l = d(end state) / d(start state); the 63 matching conditions U_{l+1} = F_l(U_l) are then solved by Newton's
+// method, whose linear system is the affine recurrence
+//     U_{l+1}^new = F_l(U_l) + A_l (U_l^new - U_l),          U_0 = x_0 fixed,
+// i.e. one wave-level affine prefix scan over the lanes.  Properties: (i) the nonlinearity is resolved exactly inside the
+// segments, only the 63 junctions are linearised, so the error squares per sweep from any reasonable guess; (ii) a
+// junction whose predecessor did not move gets EXACTLY F_l(U_l), so after j sweeps the first j segments are bitwise the
+// sequential recursion and the method terminates with the sequential result after at most 64 sweeps whatever the guess;
+// (iii) the trajectory entries are stored by the segment recursions themselves.  Sweeps repeat until no junction moved
+// by more than 1e-13 (relative).  Segments started from a useless guess may overflow; that is harmless (the exact prefix
+// reaches them), and where the true recursion itself overflows the NaNs are the result.  A block that is still not
+// settled after MAXS sweeps is integrated sequentially by lane 0: same result (counted in work.nfallback).
+// gsel: guess trajectory: 1 = the destination buffer itself (previous iterate), 2 = the state's trajectory (slot cur),
+// 3 = work.trajw (the last iterate of the retraction that produced the point being evaluated).
+template <class M, int RM>
+__global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int which, int qsel, int use_nw, int store_traj,
+                                                int gsel) {
+  // (ii) makes the sweeps exact after at most 64 of them, but a block that is not settled after a dozen belongs to a
+  // chain whose retraction is diverging (healthy blocks settle in 2-9 sweeps): it is handed to the sequential
+  // recursion, which costs the same 0.9 ms as the remaining sweeps would
+  constexpr int X = M::X, V = M::V, MAXS = 12;
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x;
+  if (wid >= sy.B * sy.K) return;
+  const int cbi = sy.order[wid];
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (use_nw ? w.nw[c] == 0 : !w.ok[c]) return;
+  if (use_nw && w.nw[c] != 1) {
+    // (K = 1) the scan of this chain's current iterate was handed to the side stream in the previous round and is
+    // done: the chain re-joins the loop with that result (its iterate has not changed meanwhile)
+    if (lane == 0 && w.nw[c] == 3) w.nw[c] = 1;
+    return;
+  }
+  const BlockDesc bd = sy.blk[b];
+  const int s_ = sl.cur[c] ^ which;
+  const int S = sy.S, L = bd.nsteps;
+  const double* q = (qsel ? w.qb : pick(sl.q, s_)) + (size_t)c * sy.Q;
+  const double* xobs = sy.xobs + (size_t)c * sy.T * X;
+  const size_t toff = (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  double* traj = (store_traj == 2 ? w.trajw : pick(sl.traj, s_)) + toff;
+  const double* guess = gsel == 2 ? pick(sl.traj, sl.cur[c]) + toff : gsel == 3 ? w.trajw + toff : traj;
+  const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const double* nn = q + sy.U + sy.NV;
+  double* out = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  const double sig = sy.noisy ? sigma_at(sy, q) : 0.0;
+  double x0[X];
+  if (bd.first) {
+    M::gx0(cc.z, q + sy.U, x0);
+  } else {
+#pragma unroll
+    for (int a = 0; a < X; ++a) x0[a] = xobs[(bd.obs0 - 1) * X + a];
+  }
+  const int m = (L + 63) >> 6;                            // steps per segment
+  const int s0 = lane * m, s1 = (s0 + m < L ? s0 + m : L);  // this lane's segment [s0, s1) (empty when s0 >= L)
+  const bool have = s0 < L;
+  double Ul[X];  // start state of this lane's segment
+#pragma unroll
+  for (int a = 0; a < X; ++a) Ul[a] = lane == 0 ? x0[a] : (have ? guess[(size_t)s0 * X + a] : 0.0);
+  bool converged = false;
+  for (int sweep = 0; sweep < MAXS && !converged; ++sweep) {
+    // exact recursion over the segment, its transition matrix, the trajectory entries and the constraint values
+    double x[X], P[X * X];
+#pragma unroll
+    for (int a = 0; a < X; ++a) x[a] = Ul[a];
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) P[i] = (i / X == i % X) ? 1.0 : 0.0;
+    for (int s = s0; s < s1; ++s) {
+      double vv[V], A[X * X], Bm[X * V], xn[X], Pn[X * X];
+#pragma unroll
+      for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
+#pragma unroll
+      for (int a = 0; a < X; ++a) traj[(size_t)s * X + a] = x[a];
+      M::jac_ab(cc.k, x, vv, A, Bm);
+      M::step(cc.k, x, vv, xn);
+      matmul_xx<X>(A, P, Pn);
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) P[i] = Pn[i];
+#pragma unroll
+      for (int a = 0; a < X; ++a) x[a] = xn[a];
+      if ((s + 1) % S == 0) {  // s + 1 is the time of local observation j
+        const int j = (s + 1) / S - 1;
+        if (j < bd.ny) out[j] = (M::obs(x) + (sy.noisy ? sig * nn[bd.obs0 + j] : 0.0)) - sy.y[bd.obs0 + j];
+      }
+    }
+    // junction defects e_l = F_l(U_l) - U_{l+1} and the Newton system d_{l+1} = e_l + A_l d_l, d_0 = 0, by an inclusive
+    // affine prefix scan over the lanes: after it (Pc, ec)_l maps d_0 to d_{l+1}, i.e. ec_l = d_{l+1}
+    double ec[X], Pc[X * X], Unext[X];
+#pragma unroll
+    for (int a = 0; a < X; ++a) Unext[a] = __shfl_down(Ul[a], 1, 64);
+    const bool junction = have && s1 < L;  // lane l + 1 owns a segment
+#pragma unroll
+    for (int a = 0; a < X; ++a) ec[a] = junction ? x[a] - Unext[a] : 0.0;
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) Pc[i] = junction ? P[i] : ((i / X == i % X) ? 1.0 : 0.0);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      double Pp[X * X], ep[X], Pn[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Pp[i] = __shfl_up(Pc[i], o, 64);
+#pragma unroll
+      for (int a = 0; a < X; ++a) ep[a] = __shfl_up(ec[a], o, 64);
+      if (lane >= o) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) {
+          double tt = ec[a];
+#pragma unroll
+          for (int d = 0; d < X; ++d) tt += Pc[a * X + d] * ep[d];
+          ec[a] = tt;
+        }
+        matmul_xx<X>(Pc, Pp, Pn);
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Pc[i] = Pn[i];
+      }
+    }
+    // d_l of this lane = ec of lane l - 1; new start state of the NEXT lane's segment, formed as F_l + A_l d_l so that a
+    // junction whose predecessor did not move (d_l == 0) receives exactly F_l
+    double dl[X], Un[X];
+#pragma unroll
+    for (int a = 0; a < X; ++a) {
+      const double up = __shfl_up(ec[a], 1, 64);
+      dl[a] = lane == 0 ? 0.0 : up;
+    }
+    bool still = true;  // this lane's start state did not move at all: its end state is final (exact prefix)
+#pragma unroll
+    for (int a = 0; a < X; ++a) still = still && dl[a] == 0.0;
+#pragma unroll
+    for (int a = 0; a < X; ++a) {
+      double tt = 0.0;
+#pragma unroll
+      for (int d = 0; d < X; ++d) tt += P[a * X + d] * dl[d];
+      Un[a] = still ? x[a] : x[a] + tt;  // (no 0 * inf from an overflowed transition matrix)
+    }
+    // A junction is settled when its new value equals the old one (bitwise, or both NaN: beyond a point where the true
+    // recursion overflows everything is NaN and stays NaN) or differs by rounding only.  Segments started from garbage
+    // may overflow; that is not an error: the exact prefix grows by at least one segment per sweep and reaches them.
+    int unsettled = 0;
+#pragma unroll
+    for (int a = 0; a < X; ++a) {
+      const double nu = __shfl_up(Un[a], 1, 64);  // new start state of this lane's segment
+      if (lane > 0 && have) {
+        const double old = Ul[a];
+        const bool same = nu == old || (nu != nu && old != old);
+        const bool close = fabs(nu - old) <= 1e-13 * (fabs(nu) > 1.0 ? fabs(nu) : 1.0);
+        unsettled |= !(same || close);
+        Ul[a] = nu;
+      }
+    }
+    // end of the block: the segment that contains step L - 1 has just produced it (from its OLD start state; it is
+    // final once the sweep that follows convergence... the loop below only leaves when no junction moved)
+    if (have && s1 == L) {
+#pragma unroll
+      for (int a = 0; a < X; ++a) traj[(size_t)L * X + a] = x[a];
+      if (!bd.last) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) out[bd.ny + a] = x[a] - xobs[(bd.obs0 + bd.nobs - 1) * X + a];
+      }
+    }
+    // converged: no junction moved (beyond rounding), so what this sweep stored IS the trajectory of the start states
+    // it used
+    converged = __ballot(unsettled) == 0ULL;
+    if (converged && lane == 0 && w.nfallback) atomicAdd(w.nfallback + 1 + (sweep < 14 ? sweep : 14) + 16 * (gsel - 1), 1);
+  }
+  if (!converged && use_nw && sy.K == 1) {
+    // Inside a Newton loop with one block per chain the sequential recursion is not done here, where it would hold up the
+    // whole launch (and every kernel behind it) for one lost chain: the chain is parked (nw = 2), the side stream
+    // integrates it (KFwd with use_nw = 2) while the loop's next kernels run for the others, and it re-joins the loop one
+    // round later.  Its iteration count, status and result are those of the plain loop.
+    if (lane == 0) {
+      w.nw[c] = 2;
+      if (w.nfallback) atomicAdd(w.nfallback + 15, 1);
+    }
+    return;
+  }
+  if (!converged && lane == 0) {  // sequential recursion (same arithmetic as fwd_block_impl)
+    double x[X], xn[X];
+#pragma unroll
+    for (int a = 0; a < X; ++a) x[a] = x0[a];
+    for (int s = 0; s < L; ++s) {
+#pragma unroll
+      for (int a = 0; a < X; ++a) traj[(size_t)s * X + a] = x[a];
+      M::step(cc.k, x, vbase + (size_t)s * V, xn);
+#pragma unroll
+      for (int a = 0; a < X; ++a) x[a] = xn[a];
+      if ((s + 1) % S == 0) {
+        const int j = (s + 1) / S - 1;
+        if (j < bd.ny) out[j] = (M::obs(x) + (sy.noisy ? sig * nn[bd.obs0 + j] : 0.0)) - sy.y[bd.obs0 + j];
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < X; ++a) traj[(size_t)L * X + a] = x[a];
+    if (!bd.last) {
+#pragma unroll
+      for (int a = 0; a < X; ++a) out[bd.ny + a] = x[a] - xobs[(bd.obs0 + bd.nobs - 1) * X + a];
+    }
+    if (w.nfallback) atomicAdd(w.nfallback, 1);
+  }
+  if (lane == 0)
+    for (int i = bd.nrows; i < RM; ++i) out[i] = 0.0;  // padded constraint slots
 }
 
 // (An LDS-staged variant of the forward scan -- 8 lanes fetching one block's 128-byte tile, tiles parked in LDS with a

@@ -1,0 +1,32 @@
+"""Sweeps the time-parallel forward scan (k_fwd_par) needs on the SIR boarding-school workload, by guess source.
+usage: python tools/par_scan_stats.py [chains] [S]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from manifold_mcmc_for_diffusions_amd.workload import SirWorkload
+from manifold_mcmc_for_diffusions_amd import _lib
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+dt = float(sys.argv[3]) if len(sys.argv) > 3 else 0.25
+wl = SirWorkload(B, num_steps_per_obs=S)
+L = _lib.lib()
+L.chmc_debug_par_scan.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+
+
+def counters():
+    a = (C.c_int * 64)()
+    L.chmc_debug_par_scan(wl.ctx.h, a)
+    return np.array(a[:])
+
+
+for it in range(4):
+    wl.refresh_momentum()
+    act = np.ones(B, dtype=np.int32)
+    c0 = counters()
+    for _ in range(8):
+        r = wl.step(dt, active=act)
+        act &= (r["status"] == 0).astype(np.int32)
+    d = counters() - c0
+    print(f"traj {it}: ok {act.mean():.2f} iters {r['iters_fwd'][act == 1].mean() if act.any() else 0:.2f}; sequential fallbacks {d[0]}; sweeps to convergence "
+          f"own-previous-iterate {d[1:16].tolist()} state-trajectory {d[17:32].tolist()} last-iterate-for-state-eval {d[33:48].tolist()}")
