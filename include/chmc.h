@@ -173,6 +173,22 @@ int chmc_leapfrog_step(chmc_ctx* ctx, const double* dt, const int* active, int n
                        double constraint_tol, double position_tol, double divergence_tol, int max_iters,
                        double reverse_check_tol, int* status, int* iters_fwd, int* iters_bwd, double* rev_err);
 
+/* The single collective of a chain-sharded run: chains are independent, every rank (one process per
+ * GPU) steps its own contiguous shard with no communication, and a sampling segment ends with ONE all-gather of the
+ * traced per-chain samples over RCCL / xGMI.  (The reference runs its chains sequentially in one process,
+ * scripts/utils.py:351-363; there is no reference collective to mirror.)
+ *   chmc_comm_unique_id : rank 0 creates the 128-byte RCCL id and hands it to the other ranks by whatever means the
+ *                         launcher has (file, MPI, torch.distributed.broadcast_object_list ...)
+ *   chmc_comm_init      : every rank, same id; creates the context's communicator (collective call)
+ *   chmc_gather_samples : local_dev [count] doubles of this rank -> gathered_dev [world][count] on EVERY rank, rank-major
+ *                         (equal shards); both are device buffers of the caller; enqueued on the context's stream and
+ *                         complete when the call returns
+ *   chmc_comm_destroy   : releases the communicator (chmc_destroy does not) */
+int chmc_comm_unique_id(void* id128);
+int chmc_comm_init(chmc_ctx* ctx, const void* id128, int rank, int world);
+int chmc_gather_samples(chmc_ctx* ctx, const void* local_dev, long count, void* gathered_dev);
+int chmc_comm_destroy(chmc_ctx* ctx);
+
 /* evaluation counters since creation: {constr, jacob_constr_blocks, lu_jacob_product_blocks, chol_gram_blocks,
  * grad_log_det_sqrt_gram, leapfrog_step calls, newton iteration launches, 0} (cf. _call_counts, :1451-1461) */
 int chmc_get_counters(const chmc_ctx* ctx, long long* out8);

@@ -276,6 +276,27 @@ class ChmcContext:
                                         iptr(itf), iptr(itb), ptr(rev)), "chmc_leapfrog_step")
         return dict(status=status, iters_fwd=itf, iters_bwd=itb, rev_err=rev)
 
+    # ---- the one collective of a chain-sharded run, through the library's own RCCL binding (include/chmc.h)
+    def comm_init(self, id128, rank, world):
+        """Create this context's RCCL communicator (collective: every rank, same 128-byte id from comm_unique_id)."""
+        buf = (C.c_char * 128).from_buffer_copy(bytes(id128))
+        check(self.L.chmc_comm_init(self.h, buf, int(rank), int(world)), "chmc_comm_init")
+        self.comm_world = int(world)
+
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_char * 128)()
+        check(_lib.lib().chmc_comm_unique_id(buf), "chmc_comm_unique_id")
+        return bytes(buf)
+
+    def gather_samples_device(self, local_dev_ptr, count, gathered_dev_ptr):
+        """All-gather of `count` doubles per rank between device buffers: gathered [world][count], rank-major."""
+        check(self.L.chmc_gather_samples(self.h, C.c_void_p(local_dev_ptr), int(count), C.c_void_p(gathered_dev_ptr)),
+              "chmc_gather_samples")
+
+    def comm_destroy(self):
+        check(self.L.chmc_comm_destroy(self.h), "chmc_comm_destroy")
+
     def counters(self):
         out = (C.c_longlong * 8)()
         check(self.L.chmc_get_counters(self.h, out), "chmc_get_counters")

@@ -127,3 +127,30 @@ def test_hmc_target_on_device_buffers_and_comparator_sampler():
             se = np.sqrt(ma.var(ddof=1) / B + mb.var(ddof=1) / B)
             assert abs(ma.mean() - mb.mean()) < 4.5 * se, (mt, k, ma.mean(), mb.mean(), se)
     ctx.close()
+
+
+def test_gather_samples_through_the_c_abi():
+    """chmc_comm_unique_id / chmc_comm_init / chmc_gather_samples (RCCL all-gather bound by the library itself, no
+    torch.distributed): a one-rank communicator on the GPU of this box -- the gathered block is the local block.  (More
+    ranks need more GPUs; the N-rank logic is covered on CPU by test_distributed_gloo.py and test_bench_launcher.py.)"""
+    import torch
+    from helpers import make_case, make_ctx
+    case = make_case("fhn", 6, 8, 2, True, B=5, seed=3)
+    ctx = make_ctx(case)
+    ctx.set_state(case["q"], None, case["x_obs"], 0)
+    ident = ctx.comm_unique_id()
+    assert len(ident) == 128 and any(ident)
+    ctx.comm_init(ident, 0, 1)
+    local = torch.empty((5, ctx.Q), dtype=torch.float64, device="cuda")
+    out = torch.zeros((1, 5, ctx.Q), dtype=torch.float64, device="cuda")
+    ctx.get_state_device(local.data_ptr(), None)
+    torch.cuda.synchronize()
+    ctx.gather_samples_device(local.data_ptr(), local.numel(), out.data_ptr())
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], local) and np.array_equal(local.cpu().numpy(), case["q"])
+    with pytest.raises(RuntimeError, match="already has a communicator"):
+        ctx.comm_init(ident, 0, 1)
+    ctx.comm_destroy()
+    with pytest.raises(RuntimeError, match="chmc_comm_init has not been called"):
+        ctx.gather_samples_device(local.data_ptr(), local.numel(), out.data_ptr())
+    ctx.close()
