@@ -61,6 +61,10 @@ def parse():
                     help="timed region: HIP events around every n-th launch of the dominant kernel (an event pair "
                          "costs the stream ~30 us, timing every launch slows the region by ~5 %%)")
     ap.add_argument("--cpu-steps", type=int, default=None)
+    ap.add_argument("--cpu-autodiff-baseline", action="store_true",
+                    help="also time ONE leapfrog step of the torch.func autodiff restatement (oracle/py, the operator-for-"
+                         "operator analogue of the reference's JAX path, eager and unjitted) at BASELINE.json configs[0]'s "
+                         "shape (S = 50) on one core: about two minutes")
     ap.add_argument("--data-steps-per-obs", type=int, default=10000, help="fine grid of the simulated FHN data")
     return ap.parse_args()
 
@@ -139,6 +143,31 @@ def cpu_baseline(wl, model, q, p, xo, part, dt, n_steps, solver, gaussian):
                                   "compiler_flags": "gcc " + c_oracle.PORTABLE_CFLAGS},
             "sample": f"{cores} chains x {n_steps} leapfrog steps from post-burn-in states, C oracle "
                       f"(oracle/c/chmc_oracle.c, gcc {flags}), one chain per host thread, {el:.1f} s"}
+
+
+def cpu_autodiff_baseline():
+    """SURVEY.md 8(d) baseline (ii): the Python restatement with torch.func fp64 autodiff standing in for JAX (jacrev of
+    a scan, grad through jacrev), one chain, one core, configs[0]'s shape (FHN noisy, T = 100, S = 50).  Eager PyTorch
+    interprets every time step in Python, which jitted XLA does not: a lower bound on what the reference's CPU path does,
+    quoted for completeness and not comparable with the compiled figures."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle.py import models as omodels, system as osys
+    from helpers import make_case
+    torch.set_num_threads(1)
+    case = make_case("fhn", 100, 50, 5, True, B=1, seed=1)
+    sysm = osys.make_system(omodels.fhn, 0.2, 50, 5, case["y"][:, None], sigma=0.1)
+    st = osys.ConditionedDiffusionHamiltonianState(case["q"][0], case["x_obs"][0], 0)
+    st.mom = sysm.sample_momentum(st, np.random.default_rng(0))
+    integ = osys.ConstrainedLeapfrogIntegrator(
+        sysm, step_size=0.05, projection_solver=osys.jitted_solve_projection_onto_manifold_newton,
+        projection_solver_kwargs=dict(constraint_tol=1e-9, position_tol=1e-8, max_iters=50))
+    t0 = time.perf_counter()
+    integ.step(st)
+    el = time.perf_counter() - t0
+    return {"value": 1.0 / el, "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": f"1 chain x 1 leapfrog step, torch.func autodiff restatement (oracle/py), FHN noisy T=100 S=50 "
+                      f"(configs[0] shape, dim_q 10106), eager PyTorch on one core, {el:.0f} s"}
 
 
 def _finite(o):
@@ -409,6 +438,8 @@ def main():
             n_cpu = a.cpu_steps if a.cpu_steps is not None else (250 if model == "fhn" and S >= 400 else 400)
             out["cpu_baseline"] = cpu_baseline(wl, model, q, p, xo, part, step_size, n_cpu, wl.solver, gaussian)
             out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+            if a.cpu_autodiff_baseline:
+                out["cpu_baseline"]["autodiff_restatement_S50"] = cpu_autodiff_baseline()
         print(json.dumps(_finite(out)), flush=True)
     D.barrier()
     ctx.close()
