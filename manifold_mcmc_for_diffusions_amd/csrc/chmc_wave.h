@@ -1253,6 +1253,290 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
   }
 }
 
+// The same backward sweep for 16-row blocks.  With 16 rows the row loops of k_gld_bwd_wave cannot be unrolled (register
+// file) and, rolled, they index per-lane arrays at run time, which puts those arrays into scratch memory (4.0 ms per
+// launch on the SIR single-block layout).  Here the row loop stays rolled but everything it indexes by the row lives in
+// LDS (the carried adjoint rows, which are wave-uniform, next to (G^-1)_bb and zd) or in global memory; the stored rows of
+// the lane's step are loaded with static indices and stay in registers.
+template <class M, int RM>
+__global__ void __launch_bounds__(256) k_gld_bwd_wave_ldsrows(Sys sy, Slots sl, Work w, int which) {
+  constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0, NXI = M::NXI;
+  __shared__ double sm[4][RM * RM + RM * Z + RM * X];
+  const int lane = threadIdx.x & 63;
+  const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wid = blockIdx.x * (blockDim.x >> 6) + wv_;
+  if (wid >= sy.B * sy.K) return;
+  const int cbi = sy.order[wid];  // work order: longest blocks first
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (!w.ok[c]) return;
+  const BlockDesc bd = sy.blk[b];
+  const int s_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int S = sy.S, NV = sy.NV;
+  const size_t TS = (size_t)sy.T * S;
+  const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* Jv = pick(sl.Jv, s_) + (size_t)c * RM * NV;
+  const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
+  const double* Xd = w.Xd + (size_t)c * RM * X * TS + bd.step0;
+  double* gv = pick(sl.grad, s_) + (size_t)c * sy.Q + sy.U;
+  double* Mb = sm[wv_];
+  double* zd = sm[wv_] + RM * RM;
+  double* Lam = sm[wv_] + RM * RM + RM * Z;  // the carried adjoint rows (wave-uniform): indexed by the row at run time
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int i = lane; i < RM * RM; i += 64) Mb[i] = w.gMb[cb * RM * RM + i];
+  for (int i = lane; i < RM * Z; i += 64) zd[i] = w.gzd[cb * RM * Z + i];
+  for (int i = lane; i < RM * X; i += 64) Lam[i] = 0.0;
+  lds_sync();
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  double xb[X], zbt[Z];
+#pragma unroll
+  for (int i = 0; i < X; ++i) xb[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < Z; ++i) zbt[i] = 0.0;
+  const int ntile = (S + 63) >> 6;
+  for (int j = bd.nobs - 1; j >= 0; --j) {
+    if (j < bd.ny) {
+      double g[X], hv[X], xt[X];
+      for (int a = 0; a < X; ++a) xt[a] = w.gxdt[(cb * RM + j) * X + a];
+      M::obs_grad(traj + (size_t)(j + 1) * S * X, g);
+      M::obs_hess_vec(traj + (size_t)(j + 1) * S * X, xt, hv);
+      {
+        double gl = 0.0;
+#pragma unroll
+        for (int a = 0; a < X; ++a) gl = lane == a ? g[a] : gl;
+        if (lane < X) Lam[j * X + lane] = gl;
+      }
+#pragma unroll
+      for (int a = 0; a < X; ++a) xb[a] += hv[a];
+    }
+    if (j == bd.nobs - 1 && !bd.last) {
+      if (lane < X) Lam[(bd.ny + lane) * X + lane] = 1.0;
+    }
+    lds_sync();
+    for (int t = ntile - 1; t >= 0; --t) {
+      const int off = (t << 6) + lane;
+      const bool valid = off < S;
+      const int s = j * S + off;
+      const size_t col = colb + (size_t)s * V;
+      double A[X * X], Bm[X * V], Zf[X * Z], x[X], vv[V];
+      if (valid) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) x[a] = ld_stream(traj + (size_t)s * X + a);
+#pragma unroll
+        for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
+        M::jac(cc.k, x, vv, A, Bm, Zf);
+      } else {
+#pragma unroll
+        for (int a = 0; a < X; ++a) x[a] = 0.0;
+#pragma unroll
+        for (int a = 0; a < V; ++a) vv[a] = 0.0;
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+      }
+      // matrix suffix scan (adjoint rows)
+      double Inc[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        double Y[X * X], Pn[X * X];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o, 64);
+        matmul_xx<X>(Y, Inc, Pn);
+        if (lane + o < 64) {
+#pragma unroll
+          for (int i = 0; i < X * X; ++i) Inc[i] = Pn[i];
+        }
+      }
+      double E[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) {
+        const double y = __shfl_down(Inc[i], 1, 64);
+        E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
+      }
+      // Hessian contraction source of this step
+      double H[NXI];
+      {
+        double Sm[X * NXI];
+#pragma unroll
+        for (int i = 0; i < X * NXI; ++i) Sm[i] = 0.0;
+        double jp[RM * V];  // stored rows at this lane's step: static indices (registers)
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+          const bool act = valid && i >= j && i < bd.nrows;
+#pragma unroll
+          for (int d = 0; d < V; ++d) jp[i * V + d] = act ? Jv[(size_t)i * NV + col + d] : 0.0;
+        }
+#pragma unroll 1
+        for (int i = 0; i < RM; ++i) {  // rolled: everything indexed by i lives in LDS or global memory
+          double Ls[X], dir[NXI];
+#pragma unroll
+          for (int d = 0; d < X; ++d) {
+            double tt = 0.0;
+#pragma unroll
+            for (int a = 0; a < X; ++a) tt += Lam[i * X + a] * E[a * X + d];
+            Ls[d] = tt;
+          }
+#pragma unroll
+          for (int a = 0; a < X; ++a) dir[a] = (valid && i >= j && i < bd.nrows) ? Xd[(size_t)(i * X + a) * TS + s] : 0.0;
+#pragma unroll
+          for (int d = 0; d < V; ++d) {
+            double tt = 0.0;
+#pragma unroll
+            for (int jj = 0; jj < RM; ++jj) tt += Mb[i * RM + jj] * jp[jj * V + d];
+            dir[X + d] = tt;
+          }
+#pragma unroll
+          for (int mz = 0; mz < Z; ++mz) dir[X + V + mz] = zd[i * Z + mz];
+#pragma unroll
+          for (int a = 0; a < X; ++a)
+#pragma unroll
+            for (int m2 = 0; m2 < NXI; ++m2) Sm[a * NXI + m2] += Ls[a] * dir[m2];
+        }
+        M::hess(cc.k, x, vv, Sm, H);
+        if (!valid) {
+#pragma unroll
+          for (int i = 0; i < NXI; ++i) H[i] = 0.0;
+        }
+      }
+      // joint suffix scan for x-bar: x-bar^(l) = x-bar^(l+1) A_l + Hx_l
+      double I2[X * X], gi[X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) I2[i] = A[i];
+#pragma unroll
+      for (int a = 0; a < X; ++a) gi[a] = H[a];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        double Y[X * X], gp[X], Pn[X * X];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(I2[i], o, 64);
+#pragma unroll
+        for (int a = 0; a < X; ++a) gp[a] = __shfl_down(gi[a], o, 64);
+        if (lane + o < 64) {
+#pragma unroll
+          for (int d = 0; d < X; ++d) {
+            double tt = gi[d];
+#pragma unroll
+            for (int a = 0; a < X; ++a) tt += gp[a] * I2[a * X + d];
+            gi[d] = tt;
+          }
+          matmul_xx<X>(Y, I2, Pn);
+#pragma unroll
+          for (int i = 0; i < X * X; ++i) I2[i] = Pn[i];
+        }
+      }
+      double xbs[X];  // x-bar at the state after this lane's step
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        const double ge = __shfl_down(gi[d], 1, 64);
+        double tt = lane == 63 ? 0.0 : ge;
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += xb[a] * E[a * X + d];
+        xbs[d] = tt;
+      }
+      if (valid) {
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          double tt = H[X + d];
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt += Bm[a * V + d] * xbs[a];
+          gv[col + d] = tt;
+        }
+      }
+#pragma unroll
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt = H[X + V + mz];
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += Zf[a * Z + mz] * xbs[a];
+        zbt[mz] += tt;
+      }
+      // carries
+      double I0[X * X], g0[X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) I0[i] = bcast0(I2[i]);
+#pragma unroll
+      for (int a = 0; a < X; ++a) g0[a] = bcast0(gi[a]);
+      {
+        double nb[X];
+#pragma unroll
+        for (int d = 0; d < X; ++d) {
+          double tt = g0[d];
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt += xb[a] * I0[a * X + d];
+          nb[d] = tt;
+        }
+#pragma unroll
+        for (int d = 0; d < X; ++d) xb[d] = nb[d];
+      }
+      {  // Lam <- Lam I0: entry e = (row, component) by lane e
+        double nl = 0.0;
+        const int e = lane < RM * X ? lane : 0, ei = e / X, ed = e - ei * X;
+#pragma unroll
+        for (int a = 0; a < X; ++a) {
+          double i0 = 0.0;
+#pragma unroll
+          for (int d = 0; d < X; ++d) i0 = d == ed ? I0[a * X + d] : i0;
+          nl += Lam[ei * X + a] * i0;
+        }
+        lds_sync();
+        if (lane < RM * X) Lam[e] = nl;
+        lds_sync();
+      }
+    }
+  }
+  if (bd.first && lane == 0) {
+    double dz[X * Z], dv0[X * V0];
+    M::gx0_jac(dz, dv0);
+    for (int d = 0; d < V0; ++d) {
+      double tt = 0.0;
+      for (int a = 0; a < X; ++a) tt += dv0[a * V0 + d] * xb[a];
+      gv[d] = tt;
+    }
+    for (int mz = 0; mz < Z; ++mz) {
+      double tt = 0.0;
+      for (int a = 0; a < X; ++a) tt += dz[a * Z + mz] * xb[a];
+      zbt[mz] += tt;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < Z; ++i) {
+    double v = zbt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    zbt[i] = v;
+  }
+  if (lane == 0) {
+    double Gz[Z * Z], gu[U];
+    M::gz_jac(q, Gz);
+    for (int d = 0; d < Z; ++d) {
+      double tt = 0.0;
+      for (int mz = 0; mz < Z; ++mz) tt += Gz[mz * Z + d] * zbt[mz];
+      gu[d] = tt;
+    }
+    for (int i = 0; i < RM; ++i) {
+      double o[Z], wu[U], zb[Z];
+      for (int d = 0; d < U; ++d) wu[d] = w.gWu[(cb * RM + i) * U + d];
+      for (int mz = 0; mz < Z; ++mz) zb[mz] = w.zbP[(cb * RM + i) * Z + mz];
+      M::gz_hess(q, wu, zb, o);
+      for (int d = 0; d < Z; ++d) gu[d] += o[d];
+    }
+    if constexpr (M::VS)  // variable observation noise: the sigma-dependent entries of J (see var_sigma_grad_terms)
+      gu[Z] = var_sigma_grad_terms<RM>(sy, bd, q, w.gWu + cb * RM * U, U, w.gMb + cb * RM * RM,
+                                       pick(sl.grad, s_) + (size_t)c * sy.Q);
+    for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
+  }
+}
+
 // Chain part of the Woodbury solves (KSolveChain in chmc_core.h) with the blocks of a chain spread over the lanes
 // of one wavefront: lane b owns block b (K <= 64), the U x U core matrix and right-hand side are summed over the
 // lanes with shuffles, every lane solves the tiny core system redundantly, forms its block's multipliers and its
@@ -1350,6 +1634,94 @@ __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work
       double* p = (psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : psel == 3 ? pick(sl.pg, s) : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
 #pragma unroll
       for (int a = 0; a < U; ++a) p[a] -= du[a];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// KNewtonFactor for 16-row blocks with the ROWS of the block over 16 lanes (four blocks per wavefront) instead of one
+// lane per block: a 16 x 16 matrix does not fit one lane's registers (the functor lives in scratch memory: 230 us per
+// launch on the SIR single-block layout, 17 launches per leapfrog step).  LU with partial pivoting in LAPACK getrf
+// order (:745-752) on the augmented rows [D | c | dc/du]: pivot search and row exchange by 16-lane shuffles, the
+// elimination of a column is one FMA per lane and entry, the forward substitution rides along (same operation order as
+// lu_solve), the back substitution runs column by column.  Then E = D^-1 dc/du, t = D^-1 c, C_b and s_b as KNewtonFactor.
+template <class M, int RM>
+__global__ void __launch_bounds__(64) k_newton_factor_wave(Sys sy, Slots sl, Work w, int prev) {
+  static_assert(RM == 16, "rows over 16 lanes");
+  constexpr int U = M::U, NC = RM + 1 + U;  // augmented row: D row | c | dc/du row
+  const int lane = threadIdx.x & 63, r = lane & 15;
+  const int tid = blockIdx.x * 4 + (lane >> 4);
+  const bool live = tid < sy.B * sy.K;
+  const int tc = live ? tid : 0;
+  const int c = tc / sy.K, b = tc - c * sy.K;
+  const bool act = live && w.nw[c] == 1;
+  const int sp = sl.cur[c] ^ prev;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  double a[NC];
+#pragma unroll
+  for (int k = 0; k < RM; ++k) a[k] = act ? w.Dw[cb * RM * RM + r * RM + k] : (k == r ? 1.0 : 0.0);
+  a[RM] = act ? w.cpad[cb * RM + r] : 0.0;
+#pragma unroll
+  for (int d = 0; d < U; ++d) a[RM + 1 + d] = act ? w.JuL[cb * RM * U + r * U + d] : 0.0;
+#pragma unroll
+  for (int j = 0; j < RM; ++j) {
+    // pivot: largest |a_ij| over the rows i >= j, the first one on ties
+    double best = r >= j ? fabs(a[j]) : -1.0;
+    int bi = r;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(best, o, 16);
+      const int oi = __shfl_xor(bi, o, 16);
+      if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+    }
+    const int p = bi;  // (uniform over the 16 lanes of the block)
+    const int partner = r == j ? p : (r == p ? j : r);
+    double pr[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      a[k] = __shfl(a[k], partner, 16);  // exchange rows j and p
+      pr[k] = __shfl(a[k], j, 16);       // the pivot row
+    }
+    const double inv = 1.0 / pr[j];
+    if (r > j) {
+      const double l = a[j] * inv;
+      a[j] = l;
+#pragma unroll
+      for (int k = j + 1; k < NC; ++k) a[k] -= l * pr[k];
+    }
+  }
+  // back substitution of the 1 + U right-hand sides, column by column
+#pragma unroll
+  for (int k = RM - 1; k >= 0; --k) {
+    const double ukk = __shfl(a[k], k, 16);
+#pragma unroll
+    for (int d = 0; d < 1 + U; ++d) {
+      const double xk = __shfl(a[RM + d], k, 16) / ukk;
+      if (r == k) a[RM + d] = xk;
+      if (r < k) a[RM + d] -= a[k] * xk;
+    }
+  }
+  if (act) {
+    w.tpad[cb * RM + r] = a[RM];
+#pragma unroll
+    for (int d = 0; d < U; ++d) w.Ew[cb * RM * U + r * U + d] = a[RM + 1 + d];
+  }
+  // C_b = Ju_prev^T E, s_b = Ju_prev^T t: sums over the 16 rows
+  double jur[U];
+#pragma unroll
+  for (int d = 0; d < U; ++d) jur[d] = act ? pick(sl.JuP, sp)[cb * RM * U + r * U + d] : 0.0;
+#pragma unroll
+  for (int aa = 0; aa < U; ++aa) {
+    double v = jur[aa] * a[RM];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    if (act && r == 0) w.sb[cb * U + aa] = v;
+#pragma unroll
+    for (int d = 0; d < U; ++d) {
+      double t = jur[aa] * a[RM + 1 + d];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 16);
+      if (act && r == 0) w.Cb[(cb * U + aa) * U + d] = t;
     }
   }
 }
