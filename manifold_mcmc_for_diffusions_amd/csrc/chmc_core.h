@@ -126,8 +126,9 @@ struct Work {
   double* dt;       // [B]
   double* part;     // [B][NPART] partial sums
   int* iters;       // [B]
-  int* nw;          // [B] Newton loop: 0 finished, 1 iterating, 2 / 3 forward scan of the current iterate handed to the
-                    //     side stream (pending / done): the chain sits this round of the loop out (k_fwd_par, K = 1)
+  int* nw;          // [B] Newton loop: 0 finished, 1 iterating; 16 + g / 32 + g: the forward scan of the current iterate
+                    //     was handed to the side stream in a round with (round & 3) == g and is pending / done -- the
+                    //     chain sits out the rounds until the loop picks it up again (k_fwd_par, K = 1)
   int* ok;          // [B] chain still good in this step
   int* status;      // [B]
   int* nstat;       // [B] status of last projection
@@ -579,7 +580,7 @@ struct KFwd {
   int which, qsel, use_nw, store_traj;
   CHMC_HD void operator()(int tid) const {
     CHMC_CB_DECODE
-    if (use_nw ? w.nw[c] != use_nw : !w.ok[c]) return;  // (use_nw 2: the deferred scans of the side stream)
+    if (use_nw ? w.nw[c] != use_nw : !w.ok[c]) return;  // (use_nw 16 + g: the deferred scans of the side stream)
     const int s = sl.cur[c] ^ which;
     const double* q = (qsel ? w.qb : pick(sl.q, s)) + (size_t)c * sy.Q;
     ChainConsts<M> cc;
@@ -591,7 +592,7 @@ struct KFwd {
     fwd_block<M, RM>(sy, bd, cc, q, sy.xobs + (size_t)c * sy.T * M::X, traj, cp);
     double* out = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
     for (int i = 0; i < RM; ++i) out[i] = cp[i];
-    if (use_nw == 2) w.nw[c] = 3;  // deferred scan done: the chain re-joins the loop in the next round (K = 1)
+    if (use_nw >= 16) w.nw[c] = use_nw + 16;  // deferred scan done: the chain re-joins the loop two rounds on (K = 1)
   }
 };
 

@@ -388,6 +388,195 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   }
 }
 
+// Reverse sweep for 16-row blocks with the row-indexed state in LDS (see k_gld_bwd_wave_ldsrows: at 16 rows the fully
+// unrolled k_rev_wave<.., GRAM = false> keeps 48 + 64 + 48 doubles of rows per lane and spills).  The row loop is rolled;
+// the carried adjoint rows (wave-uniform) and the per-lane dc/dz partial sums (one LDS column per lane, conflict-free)
+// are indexed by the row at run time; a row's dc/dv entries are stored as soon as they are formed.  MODE as k_rev_wave:
+// 0 = state evaluation (rows into the slot, dc/du rows into the slot, dc/dz rows into work.zbP), 1 = Newton iterate
+// (rows into work.JvW, dc/du rows into work.JuL).  The Gram block is formed afterwards by k_gram_rows.
+template <class M, int RM, int MODE>
+__global__ void __launch_bounds__(64) k_rev_wave_ldsrows(Sys sy, Slots sl, Work w, int which, int qsel) {
+  constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0;
+  __shared__ double LamS[RM * X];
+  __shared__ double zaccS[RM * Z * 64];
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x;
+  if (wid >= sy.B * sy.K) return;
+  const int cbi = sy.order[wid];
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (MODE == 1 ? w.nw[c] != 1 : !w.ok[c]) return;
+  const BlockDesc bd = sy.blk[b];
+  const int sl_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int S = sy.S, NV = sy.NV;
+  const double* q = (MODE == 1 ? (qsel ? w.qb : pick(sl.q, sl_ ^ 1)) : pick(sl.q, sl_)) + (size_t)c * sy.Q;
+  const double* traj = (MODE == 1 ? w.trajw : pick(sl.traj, sl_)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  double* Jo = (MODE == 1 ? w.JvW : pick(sl.Jv, sl_)) + (size_t)c * RM * NV;
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int i = lane; i < RM * X; i += 64) LamS[i] = 0.0;
+  for (int i = 0; i < RM * Z; ++i) zaccS[i * 64 + lane] = 0.0;
+  lds_sync();
+  const int ntile = (S + 63) >> 6;
+  struct Raw {
+    double x[X], v[V];
+    bool valid;
+    int s;
+  };
+  auto fetch = [&](int tt, Raw& r) {
+    const int jj = tt / ntile, t = tt - jj * ntile;
+    const int off = (t << 6) + lane;
+    r.valid = tt >= 0 && off < S;
+    r.s = jj * S + off;
+#pragma unroll
+    for (int a = 0; a < X; ++a) r.x[a] = r.valid ? ld_stream(traj + (size_t)r.s * X + a) : 0.0;
+#pragma unroll
+    for (int a = 0; a < V; ++a) r.v[a] = r.valid ? vbase[(size_t)r.s * V + a] : 0.0;
+  };
+  Raw r0, r1;
+  fetch(bd.nobs * ntile - 1, r0);
+  for (int tt = bd.nobs * ntile - 1; tt >= 0; --tt) {
+    const int j = tt / ntile, t = tt - j * ntile;
+    fetch(tt - 1, r1);  // next (earlier) tile's raw inputs
+    if (t == ntile - 1) {  // rows that start at the end of observation interval j
+      if (j < bd.ny) {
+        double g[X], gl = 0.0;
+        M::obs_grad(traj + (size_t)(j + 1) * S * X, g);
+#pragma unroll
+        for (int a = 0; a < X; ++a) gl = lane == a ? g[a] : gl;
+        if (lane < X) LamS[j * X + lane] = gl;
+      }
+      if (j == bd.nobs - 1 && !bd.last) {
+        if (lane < X) LamS[(bd.ny + lane) * X + lane] = 1.0;
+      }
+      lds_sync();
+    }
+    double A[X * X], Bm[X * V], Zf[X * Z];
+    if (r0.valid) {
+      M::jac(cc.k, r0.x, r0.v, A, Bm, Zf);
+    } else {
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+      for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+    }
+    double Inc[X * X];  // inclusive suffix products (later steps on the left)
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      double Y[X * X], P[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o, 64);
+      matmul_xx<X>(Y, Inc, P);
+      if (lane + o < 64) {
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Inc[i] = P[i];
+      }
+    }
+    double E[X * X], I0[X * X];
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) {
+      const double y = __shfl_down(Inc[i], 1, 64);
+      E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
+      I0[i] = bcast0(Inc[i]);
+    }
+    const size_t col = colb + (size_t)r0.s * V;
+#pragma unroll 1
+    for (int i = 0; i < RM; ++i) {  // rolled: everything indexed by i lives in LDS or global memory
+      double Ls[X];
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        double tt2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt2 += LamS[i * X + a] * E[a * X + d];
+        Ls[d] = tt2;
+      }
+      if (r0.valid) {
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          double tt2 = 0.0;
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt2 += Ls[a] * Bm[a * V + d];
+          Jo[(size_t)i * NV + col + d] = tt2;
+        }
+      }
+#pragma unroll
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt2 = zaccS[(i * Z + mz) * 64 + lane];
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt2 += Ls[a] * Zf[a * Z + mz];
+        zaccS[(i * Z + mz) * 64 + lane] = tt2;
+      }
+    }
+    {  // Lam <- Lam I0: entry e = (row, component) by lane e
+      double nl = 0.0;
+      const int e = lane < RM * X ? lane : 0, ei = e / X, ed = e - ei * X;
+#pragma unroll
+      for (int a = 0; a < X; ++a) {
+        double i0 = 0.0;
+#pragma unroll
+        for (int d = 0; d < X; ++d) i0 = d == ed ? I0[a * X + d] : i0;
+        nl += LamS[ei * X + a] * i0;
+      }
+      lds_sync();
+      if (lane < RM * X) LamS[e] = nl;
+      lds_sync();
+    }
+    r0 = r1;
+  }
+  // x_0 = generate_x_0(z, v_0): the v_0 columns and the z-dependence of the first block (lane 0's share)
+  if (bd.first && lane == 0) {
+    double dz[X * Z], dv0[X * V0];
+    M::gx0_jac(dz, dv0);
+    for (int i = 0; i < RM; ++i) {
+      for (int d = 0; d < V0; ++d) {
+        double tt = 0.0;
+        for (int a = 0; a < X; ++a) tt += LamS[i * X + a] * dv0[a * V0 + d];
+        Jo[(size_t)i * NV + d] = tt;
+      }
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt = 0.0;
+        for (int a = 0; a < X; ++a) tt += LamS[i * X + a] * dz[a * Z + mz];
+        zaccS[(i * Z + mz) * 64] += tt;
+      }
+    }
+  }
+  lds_sync();
+  // dc/dz rows: sums over the lanes; entry e by lane e (RM Z = 64 entries for 16 rows)
+  double G[Z * Z];
+  M::gz_jac(q, G);
+  double* ju = (MODE == 0 ? pick(sl.JuP, sl_) : w.JuL) + cb * RM * U;
+  for (int e0 = 0; e0 < RM * Z; e0 += 64) {
+    const int e = e0 + lane;
+    double sum = 0.0;
+    if (e < RM * Z)
+      for (int l = 0; l < 64; ++l) sum += zaccS[e * 64 + ((l + lane) & 63)];  // (rotated: conflict-free)
+    lds_sync();
+    if (e < RM * Z) zaccS[e * 64] = sum;
+    lds_sync();
+    if (MODE == 0 && e < RM * Z) w.zbP[cb * RM * Z + e] = sum;
+  }
+  for (int e = lane; e < RM * U; e += 64) {  // dc/du rows through generate_z'(u); the sigma column with variable noise
+    const int i = e / U, d = e - i * U;
+    double tt = 0.0;
+    if (d < Z) {
+      for (int mz = 0; mz < Z; ++mz) tt += zaccS[(i * Z + mz) * 64] * G[mz * Z + d];
+    } else {
+      tt = i < bd.ny ? sigma_at(sy, q) * q[sy.U + sy.NV + bd.obs0 + i] : 0.0;
+    }
+    ju[e] = tt;
+  }
+}
+
 // Gram block of a (chain, block) from stored rows (16-row blocks, see k_rev_wave<.., GRAM = false>):
 //   D = Ja Jb^T + sigma^2 on the observation rows + identity padding      (compute_D_blocks :765-792, :742-744)
 // Ja: rows of the iterate (work.JvW) or of the slot itself, Jb: stored rows of slot `which`.  One wavefront per
@@ -2002,7 +2191,7 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
 // 3 = work.trajw (the last iterate of the retraction that produced the point being evaluated).
 template <class M, int RM>
 __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int which, int qsel, int use_nw, int store_traj,
-                                                int gsel) {
+                                                int gsel, int round) {
   // (ii) makes the sweeps exact after at most 64 of them, but a block that is not settled after a dozen belongs to a
   // chain whose retraction is diverging (healthy blocks settle in 2-9 sweeps): it is handed to the sequential
   // recursion, which costs the same 0.9 ms as the remaining sweeps would
@@ -2014,9 +2203,10 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
   const int c = cbi / sy.K, b = cbi - c * sy.K;
   if (use_nw ? w.nw[c] == 0 : !w.ok[c]) return;
   if (use_nw && w.nw[c] != 1) {
-    // (K = 1) the scan of this chain's current iterate was handed to the side stream in the previous round and is
-    // done: the chain re-joins the loop with that result (its iterate has not changed meanwhile)
-    if (lane == 0 && w.nw[c] == 3) w.nw[c] = 1;
+    // (K = 1) the scan of this chain's current iterate was handed to the side stream two rounds ago, and the host has
+    // made this launch wait for that piece of side-stream work: the chain re-joins the loop with its result (its iterate
+    // has not changed meanwhile).  Flags of later rounds may be changing under our eyes and are not looked at.
+    if (lane == 0 && w.nw[c] == 32 + ((round + 2) & 3)) w.nw[c] = 1;
     return;
   }
   const BlockDesc bd = sy.blk[b];
@@ -2152,11 +2342,11 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
   }
   if (!converged && use_nw && sy.K == 1) {
     // Inside a Newton loop with one block per chain the sequential recursion is not done here, where it would hold up the
-    // whole launch (and every kernel behind it) for one lost chain: the chain is parked (nw = 2), the side stream
-    // integrates it (KFwd with use_nw = 2) while the loop's next kernels run for the others, and it re-joins the loop one
-    // round later.  Its iteration count, status and result are those of the plain loop.
+    // whole launch (and every kernel behind it) for one lost chain: the chain is parked (nw = 16 + round % 4), the side
+    // stream integrates it (KFwd with that use_nw) while the loop's next two rounds run for the others, and it re-joins
+    // the loop two rounds later.  Its iteration count, status and result are those of the plain loop.
     if (lane == 0) {
-      w.nw[c] = 2;
+      w.nw[c] = 16 + (round & 3);
       if (w.nfallback) atomicAdd(w.nfallback + 15, 1);
     }
     return;
