@@ -73,6 +73,15 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   static_assert(RM <= 8 || !GRAM, "16-row blocks: instantiate with GRAM = false and form the Gram block with k_gram_rows");
   constexpr int URM = 64;
   constexpr bool STORE_ROWS = MODE == 0 || !GRAM;
+  // dc/dz sums through a per-interval frame: within an observation interval every live adjoint row is the row at the
+  // interval's end times ONE running product of transition matrices, Lam_i(tile) = LamF_i Pf(tile), so
+  //     sum_tiles Lam_i(tile) E Zf  =  LamF_i  sum_tiles Pf(tile) (E Zf):
+  // the hot loop accumulates the X x Z matrix Wacc += Pf (E Zf) (8 sums for FitzHugh-Nagumo) instead of RM x Z sums
+  // (28), and zacc_i += LamF_i Wacc once per interval.  Fewer FMAs per tile and 20 fewer hot accumulators.
+#ifndef CHMC_REV_ZW
+#define CHMC_REV_ZW 1
+#endif
+  constexpr bool ZW = CHMC_REV_ZW && GRAM;
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= sy.B * sy.K) return;
@@ -93,6 +102,32 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
 
   double Lam[RM * X], Dacc[GRAM ? RM * RM : 1], zacc[RM * Z];
+  double LamF[ZW ? RM * X : 1], Wacc[ZW ? X * Z : 1], Pf[ZW ? X * X : 1];
+  if (ZW) {
+#pragma unroll
+    for (int i = 0; i < RM * X; ++i) LamF[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < X * Z; ++i) Wacc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) Pf[i] = (i / X == i % X) ? 1.0 : 0.0;
+  }
+  auto flush_frame = [&]() {  // zacc_i += LamF_i Wacc; the next frame starts at the current rows
+    if (ZW) {
+#pragma unroll
+      for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int mz = 0; mz < Z; ++mz) {
+          double tt2 = zacc[i * Z + mz];
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt2 += LamF[i * X + a] * Wacc[a * Z + mz];
+          zacc[i * Z + mz] = tt2;
+        }
+#pragma unroll
+      for (int i = 0; i < X * Z; ++i) Wacc[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Pf[i] = (i / X == i % X) ? 1.0 : 0.0;
+    }
+  };
 #pragma unroll URM
   for (int i = 0; i < RM * X; ++i) Lam[i] = 0.0;
 #pragma unroll
@@ -203,13 +238,40 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
         for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * sc.Bm[a * V + d];
         jr[i * V + d] = tt2;
       }
+      if (!ZW) {
 #pragma unroll
-      for (int mz = 0; mz < Z; ++mz) {
-        double tt2 = zacc[i * Z + mz];
+        for (int mz = 0; mz < Z; ++mz) {
+          double tt2 = zacc[i * Z + mz];
 #pragma unroll
-        for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * sc.Zf[a * Z + mz];
-        zacc[i * Z + mz] = tt2;
+          for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * sc.Zf[a * Z + mz];
+          zacc[i * Z + mz] = tt2;
+        }
       }
+    }
+    if (ZW) {  // Wacc += Pf (E Zf), then Pf <- Pf I0 (the frame's rows carried to the start of this tile)
+      double Wt[X * Z];
+#pragma unroll
+      for (int a = 0; a < X; ++a)
+#pragma unroll
+        for (int mz = 0; mz < Z; ++mz) {
+          double tt2 = 0.0;
+#pragma unroll
+          for (int d = 0; d < X; ++d) tt2 += sc.E[a * X + d] * sc.Zf[d * Z + mz];
+          Wt[a * Z + mz] = tt2;
+        }
+#pragma unroll
+      for (int a = 0; a < X; ++a)
+#pragma unroll
+        for (int mz = 0; mz < Z; ++mz) {
+          double tt2 = Wacc[a * Z + mz];
+#pragma unroll
+          for (int d = 0; d < X; ++d) tt2 += Pf[a * X + d] * Wt[d * Z + mz];
+          Wacc[a * Z + mz] = tt2;
+        }
+      double Pn[X * X];
+      matmul_xx<X>(Pf, sc.I0, Pn);
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Pf[i] = Pn[i];
     }
     const size_t col = colb + (size_t)r.s * V;
     if (STORE_ROWS) {
@@ -275,6 +337,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
     fetch(tt - 2, r2);
     fetch_rows(r1, w1);
     if (t == ntile - 1) {
+      flush_frame();  // the interval that has just been swept
       // rows that start at the end of observation interval j
       if (j < bd.ny) {
         double g[X];
@@ -292,6 +355,10 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
           for (int a = 0; a < X; ++a)
             if (i == bd.ny + a) Lam[i * X + a] = 1.0;
       }
+      if (ZW) {
+#pragma unroll
+        for (int i = 0; i < RM * X; ++i) LamF[i] = Lam[i];
+      }
     }
     stage1(r1, sc1);  // tile tt - 1 (identity when there is none)
     stage2(sc0, r0, w0);  // tile tt
@@ -300,6 +367,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
     w0 = w1;
     sc0 = sc1;
   }
+  flush_frame();  // the first interval
   // x_0 = generate_x_0(z, v_0): the v_0 columns and the z-dependence of the first block (lane 0's share)
   if (bd.first && lane == 0) {
     double dz[X * Z], dv0[X * V0];
