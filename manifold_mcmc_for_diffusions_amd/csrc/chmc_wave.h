@@ -73,11 +73,17 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   static_assert(RM <= 8 || !GRAM, "16-row blocks: instantiate with GRAM = false and form the Gram block with k_gram_rows");
   constexpr int URM = 64;
   constexpr bool STORE_ROWS = MODE == 0 || !GRAM;
-  // dc/dz sums through a per-interval frame: within an observation interval every live adjoint row is the row at the
-  // interval's end times ONE running product of transition matrices, Lam_i(tile) = LamF_i Pf(tile), so
-  //     sum_tiles Lam_i(tile) E Zf  =  LamF_i  sum_tiles Pf(tile) (E Zf):
-  // the hot loop accumulates the X x Z matrix Wacc += Pf (E Zf) (8 sums for FitzHugh-Nagumo) instead of RM x Z sums
-  // (28), and zacc_i += LamF_i Wacc once per interval.  Fewer FMAs per tile and 20 fewer hot accumulators.
+  // Interval frames.  Within an observation interval no row is injected, so every adjoint row at a step is the row at
+  // the interval's END (the frame LamF, wave-uniform) times ONE matrix that does not depend on the row:
+  //     Lam_i(step s) = LamF_i Pf E_s       (Pf: product of the tiles already swept, E_s: the lane's suffix product),
+  // hence, with T_s = Pf E_s B_s (X x V) and PE_s = Pf E_s,
+  //     dc_i/dv_s                = LamF_i T_s
+  //     sum_s Lam_i(s) Zf_s      = LamF_i  [ sum_s PE_s Zf_s ]                 Wacc : X x Z sums instead of RM x Z
+  //     Gram (Newton)  D_ij      = LamF_i  [ sum_s T_s (dc_j/dv_s of the stored point)^T ]     Yacc : RM x X instead of RM x RM
+  //     Gram (state)   D_ij      = LamF_i  [ sum_s T_s T_s^T ] LamF_j^T                        Sacc : X x X
+  // The hot loop therefore carries 8 + 14 (Newton) or 8 + 4 (state) running sums per lane for FitzHugh-Nagumo instead
+  // of 28 + 49, does not form the rows at all in a Newton iteration, and the RM-sized products are taken once per
+  // interval (flush_frame), where the rows for the next interval are formed as LamF Pf as well.
 #ifndef CHMC_REV_ZW
 #define CHMC_REV_ZW 1
 #endif
@@ -103,6 +109,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
 
   double Lam[RM * X], Dacc[GRAM ? RM * RM : 1], zacc[RM * Z];
   double LamF[ZW ? RM * X : 1], Wacc[ZW ? X * Z : 1], Pf[ZW ? X * X : 1];
+  double Yacc[ZW && MODE == 1 ? RM * X : 1], Sacc[ZW && MODE == 0 ? X * X : 1];
   if (ZW) {
 #pragma unroll
     for (int i = 0; i < RM * X; ++i) LamF[i] = 0.0;
@@ -110,8 +117,12 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
     for (int i = 0; i < X * Z; ++i) Wacc[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < X * X; ++i) Pf[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < (MODE == 1 ? RM * X : 1); ++i) Yacc[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < (MODE == 0 ? X * X : 1); ++i) Sacc[i] = 0.0;
   }
-  auto flush_frame = [&]() {  // zacc_i += LamF_i Wacc; the next frame starts at the current rows
+  auto flush_frame = [&]() {  // the RM-sized products of the interval just swept; its rows at its start
     if (ZW) {
 #pragma unroll
       for (int i = 0; i < RM; ++i)
@@ -121,6 +132,50 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
 #pragma unroll
           for (int a = 0; a < X; ++a) tt2 += LamF[i * X + a] * Wacc[a * Z + mz];
           zacc[i * Z + mz] = tt2;
+        }
+      if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int jj = 0; jj < RM; ++jj) {
+            double tt2 = Dacc[i * RM + jj];
+#pragma unroll
+            for (int a = 0; a < X; ++a) tt2 += LamF[i * X + a] * Yacc[jj * X + a];
+            Dacc[i * RM + jj] = tt2;
+          }
+#pragma unroll
+        for (int i = 0; i < RM * X; ++i) Yacc[i] = 0.0;
+      } else {
+        double Qi[RM * X];  // LamF Sacc (Sacc holds the upper triangle of the symmetric X x X sum)
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int bb = 0; bb < X; ++bb) {
+            double tt2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < X; ++a) tt2 += LamF[i * X + a] * (a <= bb ? Sacc[a * X + bb] : Sacc[bb * X + a]);
+            Qi[i * X + bb] = tt2;
+          }
+#pragma unroll
+        for (int i = 0; i < RM; ++i)
+#pragma unroll
+          for (int jj = 0; jj <= i; ++jj) {
+            double tt2 = Dacc[i * RM + jj];
+#pragma unroll
+            for (int bb = 0; bb < X; ++bb) tt2 += Qi[i * X + bb] * LamF[jj * X + bb];
+            Dacc[i * RM + jj] = tt2;
+          }
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Sacc[i] = 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < RM; ++i)  // the rows at the start of the swept interval
+#pragma unroll
+        for (int d = 0; d < X; ++d) {
+          double tt2 = 0.0;
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt2 += LamF[i * X + a] * Pf[a * X + d];
+          Lam[i * X + d] = tt2;
         }
 #pragma unroll
       for (int i = 0; i < X * Z; ++i) Wacc[i] = 0.0;
@@ -221,6 +276,74 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
     }
   };
   auto stage2 = [&](const Scan& sc, const Raw& r, const Rows& rw) {
+    if constexpr (ZW) {
+      double PE[X * X], T[X * V];
+      matmul_xx<X>(Pf, sc.E, PE);
+#pragma unroll
+      for (int a = 0; a < X; ++a)
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          double tt2 = 0.0;
+#pragma unroll
+          for (int e = 0; e < X; ++e) tt2 += PE[a * X + e] * sc.Bm[e * V + d];
+          T[a * V + d] = tt2;
+        }
+#pragma unroll
+      for (int a = 0; a < X; ++a)
+#pragma unroll
+        for (int mz = 0; mz < Z; ++mz) {
+          double tt2 = Wacc[a * Z + mz];
+#pragma unroll
+          for (int e = 0; e < X; ++e) tt2 += PE[a * X + e] * sc.Zf[e * Z + mz];
+          Wacc[a * Z + mz] = tt2;
+        }
+      if (MODE == 0) {
+        if (r.valid) {  // the rows of this step, dc_i/dv_s = LamF_i T_s, go straight to memory
+          const size_t col0 = colb + (size_t)r.s * V;
+#pragma unroll
+          for (int i = 0; i < RM; ++i) {
+            double jr0[V];
+#pragma unroll
+            for (int d = 0; d < V; ++d) {
+              double tt2 = 0.0;
+#pragma unroll
+              for (int a = 0; a < X; ++a) tt2 += LamF[i * X + a] * T[a * V + d];
+              jr0[d] = tt2;
+            }
+            if (V == 2) {
+              st_async2(Jo + (size_t)i * NV + col0, jr0[0], jr0[V - 1]);
+            } else {
+#pragma unroll
+              for (int d = 0; d < V; ++d) st_async(Jo + (size_t)i * NV + col0 + d, jr0[d]);
+            }
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < X; ++a)
+#pragma unroll
+          for (int bb = a; bb < X; ++bb) {
+            double tt2 = Sacc[a * X + bb];
+#pragma unroll
+            for (int d = 0; d < V; ++d) tt2 += T[a * V + d] * T[bb * V + d];
+            Sacc[a * X + bb] = tt2;
+          }
+      } else {
+#pragma unroll
+        for (int jj = 0; jj < RM; ++jj)
+#pragma unroll
+          for (int a = 0; a < X; ++a) {
+            double tt2 = Yacc[jj * X + a];
+#pragma unroll
+            for (int d = 0; d < V; ++d) tt2 += T[a * V + d] * rw.jp[jj * V + d];
+            Yacc[jj * X + a] = tt2;
+          }
+      }
+      double Pn[X * X];
+      matmul_xx<X>(Pf, sc.I0, Pn);
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Pf[i] = Pn[i];
+      return;
+    }
     double Ls[RM * X], jr[RM * V];
 #pragma unroll URM
     for (int i = 0; i < RM; ++i) {
@@ -238,40 +361,13 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
         for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * sc.Bm[a * V + d];
         jr[i * V + d] = tt2;
       }
-      if (!ZW) {
 #pragma unroll
-        for (int mz = 0; mz < Z; ++mz) {
-          double tt2 = zacc[i * Z + mz];
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt2 = zacc[i * Z + mz];
 #pragma unroll
-          for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * sc.Zf[a * Z + mz];
-          zacc[i * Z + mz] = tt2;
-        }
+        for (int a = 0; a < X; ++a) tt2 += Ls[i * X + a] * sc.Zf[a * Z + mz];
+        zacc[i * Z + mz] = tt2;
       }
-    }
-    if (ZW) {  // Wacc += Pf (E Zf), then Pf <- Pf I0 (the frame's rows carried to the start of this tile)
-      double Wt[X * Z];
-#pragma unroll
-      for (int a = 0; a < X; ++a)
-#pragma unroll
-        for (int mz = 0; mz < Z; ++mz) {
-          double tt2 = 0.0;
-#pragma unroll
-          for (int d = 0; d < X; ++d) tt2 += sc.E[a * X + d] * sc.Zf[d * Z + mz];
-          Wt[a * Z + mz] = tt2;
-        }
-#pragma unroll
-      for (int a = 0; a < X; ++a)
-#pragma unroll
-        for (int mz = 0; mz < Z; ++mz) {
-          double tt2 = Wacc[a * Z + mz];
-#pragma unroll
-          for (int d = 0; d < X; ++d) tt2 += Pf[a * X + d] * Wt[d * Z + mz];
-          Wacc[a * Z + mz] = tt2;
-        }
-      double Pn[X * X];
-      matmul_xx<X>(Pf, sc.I0, Pn);
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) Pf[i] = Pn[i];
     }
     const size_t col = colb + (size_t)r.s * V;
     if (STORE_ROWS) {
