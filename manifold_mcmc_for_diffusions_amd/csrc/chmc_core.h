@@ -133,6 +133,7 @@ struct Work {
   int* status;      // [B]
   int* nstat;       // [B] status of last projection
   int* n_active;    // [1]
+  const double* zeros;  // [256] zeros (stand-in source for loads of structurally zero Jacobian entries)
   int* nfallback;   // [1] blocks the time-parallel forward scan handed to its sequential fallback (diagnostic)
 };
 

@@ -47,6 +47,26 @@ __device__ inline double bcast0(double x) {  // value of lane 0, as a wave-unifo
   return u.d;
 }
 
+// Cross-lane moves through the DPP path of the vector ALU (no LDS crossbar, no lgkmcnt wait): dst lane <- src lane as
+// the control word says, lanes without a source (row boundaries, masked rows / banks) receive `old`.
+//   row_shr:n = 0x110 + n (shift right by n inside each row of 16 lanes), wave_shr:1 = 0x138,
+//   row_bcast:15 = 0x142 (lane 15 of each row to the next row), row_bcast:31 = 0x143 (lane 31 to rows 2 and 3)
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_mov(double x, double old) {
+  union { double d; int i[2]; } u, o;
+  u.d = x, o.d = old;
+  u.i[0] = __builtin_amdgcn_update_dpp(o.i[0], u.i[0], CTRL, ROW_MASK, BANK_MASK, false);
+  u.i[1] = __builtin_amdgcn_update_dpp(o.i[1], u.i[1], CTRL, ROW_MASK, BANK_MASK, false);
+  return u.d;
+}
+__device__ inline double bcast_lane63(double x) {  // value of lane 63, as a wave-uniform value
+  union { double d; int i[2]; } u;
+  u.d = x;
+  u.i[0] = __builtin_amdgcn_readlane(u.i[0], 63);
+  u.i[1] = __builtin_amdgcn_readlane(u.i[1], 63);
+  return u.d;
+}
+
 template <int X>
 __device__ inline void matmul_xx(const double* a, const double* b, double* c) {  // c = a b (X x X)
 #pragma unroll
@@ -58,6 +78,36 @@ __device__ inline void matmul_xx(const double* a, const double* b, double* c) { 
       for (int k = 0; k < X; ++k) t += a[i * X + k] * b[k * X + j];
       c[i * X + j] = t;
     }
+}
+
+// Inclusive PREFIX product over the 64 lanes, lower lanes on the left: P_l = A_0 A_1 ... A_l, in seven DPP steps (the
+// classic row_shr 1 / 2 / 3, row_shr 4 / 8 with bank masks, row_bcast 15 / 31 sequence).  Lanes without a source get the
+// identity, so every step is an unconditional matrix product.  On return P holds the inclusive products; E (optional)
+// the exclusive ones (identity in lane 0).
+template <int X, int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ void dpp_scan_step(double* P, const double* src) {
+  double Y[X * X], Pn[X * X];
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) Y[i] = dpp_mov<CTRL, ROW_MASK, BANK_MASK>(src[i], (i / X == i % X) ? 1.0 : 0.0);
+  matmul_xx<X>(Y, P, Pn);
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) P[i] = Pn[i];
+}
+template <int X>
+__device__ __forceinline__ void dpp_prefix_products(const double* A, double* P, double* E) {
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) P[i] = A[i];
+  dpp_scan_step<X, 0x111, 0xf, 0xf>(P, A);  // row_shr:1 of the ORIGINAL values
+  dpp_scan_step<X, 0x112, 0xf, 0xf>(P, A);  // row_shr:2
+  dpp_scan_step<X, 0x113, 0xf, 0xf>(P, A);  // row_shr:3
+  dpp_scan_step<X, 0x114, 0xf, 0xe>(P, P);  // row_shr:4, banks 1-3
+  dpp_scan_step<X, 0x118, 0xf, 0xc>(P, P);  // row_shr:8, banks 2-3
+  dpp_scan_step<X, 0x142, 0xa, 0xf>(P, P);  // row_bcast:15, rows 1 and 3
+  dpp_scan_step<X, 0x143, 0xc, 0xf>(P, P);  // row_bcast:31, rows 2 and 3
+  if (E) {
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) E[i] = dpp_mov<0x138, 0xf, 0xf>(P[i], (i / X == i % X) ? 1.0 : 0.0);  // wave_shr:1
+  }
 }
 
 // MODE 0: state evaluation -- store dc/dv rows, symmetric Gram, dc/du rows into the slot.
@@ -549,6 +599,272 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
       // d(sigma(u) n_i) / du_sigma = sigma n_i on the observation rows (g_y_bar :559-569)
       if (M::VS) ju[i * U + Z] = i < bd.ny ? sigma_at(sy, q) * q[sy.U + sy.NV + bd.obs0 + i] : 0.0;
     }
+  }
+}
+
+// Newton-iteration sweep (k_rev_wave<.., MODE 1>) rebuilt around the interval frames for TWO wavefronts per SIMD.
+// With the frames the hot loop of a Newton iteration carries only X x Z + RM x X running sums per lane, but k_rev_wave
+// still keeps the RM x RM Gram block, the RM x Z dc/dz rows and the adjoint rows per lane (210 registers that are touched
+// once per interval), which pins it at one wavefront per SIMD, where the 6-level shuffle scan of every tile is exposed
+// latency (measured: cutting its HBM bytes by 17 % changed nothing).  Here the per-interval running sums are added up
+// over the wave when an interval ends (shuffle butterfly) and everything RM-sized lives ONCE per wavefront in LDS
+// (0.9 KB): adjoint rows of the frame, Gram block, dc/dz rows, updated by one lane per entry.  The kernel fits
+// 128 registers, two wavefronts share a SIMD and fill each other's shuffle latencies.
+#ifndef CHMC_LEAN_WAVES
+#define CHMC_LEAN_WAVES 2
+#endif
+template <class M, int RM>
+__global__ void __launch_bounds__(64, CHMC_LEAN_WAVES) k_newton_lean(Sys sy, Slots sl, Work w, int which, int qsel) {
+  constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0;
+  static_assert(RM <= 8, "blocks of at most 8 rows");
+  __shared__ double LamF[RM * X], Dl[RM * RM], zl[RM * Z], Ys[RM * X], Ws[X * Z];
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x;
+  if (wid >= sy.B * sy.K) return;
+  const int cbi = sy.order[wid];  // work order: longest blocks first
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (w.nw[c] != 1) return;
+  const BlockDesc bd = sy.blk[b];
+  const int sl_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int S = sy.S, NV = sy.NV;
+  const double* q = (qsel ? w.qb : pick(sl.q, sl_ ^ 1)) + (size_t)c * sy.Q;
+  const double* traj = w.trajw + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* Jr = pick(sl.Jv, sl_) + (size_t)c * RM * NV;
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int e = lane; e < RM * X; e += 64) LamF[e] = 0.0;
+  for (int e = lane; e < RM * RM; e += 64) Dl[e] = 0.0;
+  for (int e = lane; e < RM * Z; e += 64) zl[e] = 0.0;
+  lds_sync();
+  double Wacc[X * Z], Yacc[RM * X], Pf[X * X];
+#pragma unroll
+  for (int i = 0; i < X * Z; ++i) Wacc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < RM * X; ++i) Yacc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) Pf[i] = (i / X == i % X) ? 1.0 : 0.0;
+  // end of an interval: the wave's sums, the RM-sized products (one lane per entry), the rows at the interval's start
+  auto flush_frame = [&]() {
+#pragma unroll
+    for (int i = 0; i < RM * X; ++i) {
+      double v = Yacc[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == i) Ys[i] = v;
+      Yacc[i] = 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < X * Z; ++i) {
+      double v = Wacc[i];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      if (lane == i) Ws[i] = v;
+      Wacc[i] = 0.0;
+    }
+    lds_sync();
+    double nl = 0.0;  // entry `lane` of the rows at the start of the swept interval, LamF Pf
+    if (lane < RM * X) {
+      const int i = lane / X, d = lane - i * X;
+#pragma unroll
+      for (int a = 0; a < X; ++a) {
+        double pf = 0.0;
+#pragma unroll
+        for (int dd = 0; dd < X; ++dd) pf = dd == d ? Pf[a * X + dd] : pf;
+        nl += LamF[i * X + a] * pf;
+      }
+    }
+    if (lane < RM * RM) {
+      const int i = lane / RM, jj = lane - i * RM;
+      double tt = Dl[lane];
+#pragma unroll
+      for (int a = 0; a < X; ++a) tt += LamF[i * X + a] * Ys[jj * X + a];
+      Dl[lane] = tt;
+    }
+    if (lane < RM * Z) {
+      const int i = lane / Z, mz = lane - i * Z;
+      double tt = zl[lane];
+#pragma unroll
+      for (int a = 0; a < X; ++a) tt += LamF[i * X + a] * Ws[a * Z + mz];
+      zl[lane] = tt;
+    }
+    lds_sync();
+    if (lane < RM * X) LamF[lane] = nl;
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) Pf[i] = (i / X == i % X) ? 1.0 : 0.0;
+    lds_sync();
+  };
+  const int ntile = (S + 63) >> 6;
+  struct Raw {
+    double x[X], v[V], jp[RM * V];
+    bool valid;
+  };
+  auto fetch = [&](int tt, Raw& r) {
+    const int jj = tt / ntile, t = tt - jj * ntile;
+    const int off = (t << 6) + (63 - lane);  // LATER steps in LOWER lanes: the suffix products become a prefix scan
+    r.valid = tt >= 0 && off < S;
+    const int s = jj * S + off;
+    if (r.valid) {
+#pragma unroll
+      for (int a = 0; a < X; ++a) r.x[a] = ld_stream(traj + (size_t)s * X + a);
+#pragma unroll
+      for (int a = 0; a < V; ++a) r.v[a] = vbase[(size_t)s * V + a];
+      const size_t col = colb + (size_t)s * V;
+      // Observation row i is structurally zero in the intervals after its own (jj > i): those entries are zeros in HBM.
+      // Branching around their loads would break the load pipelining, so the loads stay and are pointed at a small block
+      // of zeros that lives in the caches: same instructions, 2 of 7 rows' bytes less HBM traffic.
+#pragma unroll
+      for (int i = 0; i < RM; ++i) {
+#if 1  // (zero-block loads: -17 % HBM bytes, -1.7 % time)
+        const double* src = (i < jj && i < bd.ny) ? w.zeros + 2 * lane : Jr + (size_t)i * NV + col;
+#else
+        const double* src = Jr + (size_t)i * NV + col;
+#endif
+#pragma unroll
+        for (int d = 0; d < V; ++d) r.jp[i * V + d] = ld_stream(src + d);
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < X; ++a) r.x[a] = 0.0;
+#pragma unroll
+      for (int a = 0; a < V; ++a) r.v[a] = 0.0;
+#pragma unroll
+      for (int i = 0; i < RM * V; ++i) r.jp[i] = 0.0;
+    }
+  };
+  Raw r0, r1;
+  fetch(bd.nobs * ntile - 1, r0);
+  for (int tt = bd.nobs * ntile - 1; tt >= 0; --tt) {
+    const int j = tt / ntile, t = tt - j * ntile;
+    fetch(tt - 1, r1);
+    if (t == ntile - 1) {
+      flush_frame();  // the interval that has just been swept
+      // rows that start at the end of observation interval j
+      if (j < bd.ny) {
+        double g[X], gl = 0.0;
+        M::obs_grad(traj + (size_t)(j + 1) * S * X, g);
+#pragma unroll
+        for (int a = 0; a < X; ++a) gl = lane == a ? g[a] : gl;
+        if (lane < X) LamF[j * X + lane] = gl;
+      }
+      if (j == bd.nobs - 1 && !bd.last) {
+        if (lane < X) LamF[(bd.ny + lane) * X + lane] = 1.0;
+      }
+      lds_sync();
+    }
+    double A[X * X], Bm[X * V], Zf[X * Z];
+    if (r0.valid) {
+      M::jac(cc.k, r0.x, r0.v, A, Bm, Zf);
+    } else {
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+      for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+    }
+    // products of the transition matrices of the LATER steps of the tile (later steps on the left): with the later steps
+    // in the lower lanes an exclusive prefix product over the lanes; lane 63's inclusive product spans the tile
+    double Inc[X * X], E[X * X], I0[X * X], PE[X * X], T[X * V];
+    dpp_prefix_products<X>(A, Inc, E);
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) I0[i] = bcast_lane63(Inc[i]);
+    matmul_xx<X>(Pf, E, PE);
+#pragma unroll
+    for (int a = 0; a < X; ++a)
+#pragma unroll
+      for (int d = 0; d < V; ++d) {
+        double tt2 = 0.0;
+#pragma unroll
+        for (int e = 0; e < X; ++e) tt2 += PE[a * X + e] * Bm[e * V + d];
+        T[a * V + d] = tt2;
+      }
+#pragma unroll
+    for (int a = 0; a < X; ++a)
+#pragma unroll
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt2 = Wacc[a * Z + mz];
+#pragma unroll
+        for (int e = 0; e < X; ++e) tt2 += PE[a * X + e] * Zf[e * Z + mz];
+        Wacc[a * Z + mz] = tt2;
+      }
+#pragma unroll
+    for (int jj = 0; jj < RM; ++jj)
+#pragma unroll
+      for (int a = 0; a < X; ++a) {
+        double tt2 = Yacc[jj * X + a];
+#pragma unroll
+        for (int d = 0; d < V; ++d) tt2 += T[a * V + d] * r0.jp[jj * V + d];
+        Yacc[jj * X + a] = tt2;
+      }
+    {
+      double Pn[X * X];
+      matmul_xx<X>(Pf, I0, Pn);
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Pf[i] = Pn[i];
+    }
+    r0 = r1;
+  }
+  flush_frame();  // the first interval; LamF now holds the rows at the start of the block
+  // x_0 = generate_x_0(z, v_0): the v_0 columns and the z-dependence of the first block
+  if (bd.first) {
+    double dz[X * Z], dv0[X * V0];
+    M::gx0_jac(dz, dv0);
+    if (lane < RM * RM) {
+      const int i = lane / RM, jj = lane - i * RM;
+      double tt = Dl[lane];
+      for (int d = 0; d < V0; ++d) {
+        double j0 = 0.0;
+        for (int a = 0; a < X; ++a) j0 += LamF[i * X + a] * dv0[a * V0 + d];
+        tt += j0 * Jr[(size_t)jj * NV + d];
+      }
+      Dl[lane] = tt;
+    }
+    if (lane < RM * Z) {
+      const int i = lane / Z, mz = lane - i * Z;
+      double tt = zl[lane];
+      for (int a = 0; a < X; ++a) {
+        double dzs = 0.0;
+#pragma unroll
+        for (int e = 0; e < X * Z; ++e) dzs = e == a * Z + mz ? dz[e] : dzs;
+        tt += LamF[i * X + a] * dzs;
+      }
+      zl[lane] = tt;
+    }
+  }
+  lds_sync();
+  if (lane < RM * RM) {  // noise term on the observation rows, identity padding
+    const int i = lane / RM, jj = lane - i * RM;
+    double v = Dl[lane];
+    if (i == jj) {
+      const double sg_ = sy.noisy ? sigma_at(sy, q) : 0.0;
+      if (sy.noisy && i < bd.ny) v += sg_ * sigma_at(sy, pick(sl.q, sl_) + (size_t)c * sy.Q);  // dc_dn_l * dc_dn_r (:772-791)
+      if (i >= bd.nrows) v = 1.0;
+    }
+    w.Dw[cb * RM * RM + lane] = v;
+  }
+  double G[Z * Z];
+  M::gz_jac(q, G);
+  for (int e = lane; e < RM * U; e += 64) {  // dc/du rows of the iterate through generate_z'(u)
+    const int i = e / U, d = e - i * U;
+    double tt = 0.0;
+    if (d < Z) {
+      for (int mz = 0; mz < Z; ++mz) {
+        double gs = 0.0;
+#pragma unroll
+        for (int ee = 0; ee < Z * Z; ++ee) gs = ee == mz * Z + d ? G[ee] : gs;
+        tt += zl[i * Z + mz] * gs;
+      }
+    } else {
+      tt = i < bd.ny ? sigma_at(sy, q) * q[sy.U + sy.NV + bd.obs0 + i] : 0.0;
+    }
+    w.JuL[cb * RM * U + e] = tt;
   }
 }
 

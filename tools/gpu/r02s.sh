@@ -1,7 +1,7 @@
 R=$PWD
 mkdir -p gpurun_out/r02s
 python -m pytest tests/test_hip_parity.py tests/test_golden.py -m gpu -x -q -k "not sir and not variable" 2>&1 | tail -3
-for i in 1 2; do for lib in libchmc_hip.so libchmc_hip_zw0.so; do
+for i in 1 2; do for lib in libchmc_hip.so libchmc_hip_prev.so; do
 CHMC_HIP_LIBRARY=$R/manifold_mcmc_for_diffusions_amd/$lib python bench.py --no-cpu-baseline > gpurun_out/r02s/b_$lib.$i.json 2>/dev/null
 python - $lib $i <<'PY'
 import json,sys

@@ -1,0 +1,13 @@
+R=$PWD
+mkdir -p gpurun_out/r02u
+for i in 1 2; do for lib in libchmc_hip.so libchmc_hip_z.so libchmc_hip_w3.so libchmc_hip_w3z.so libchmc_hip_w4z.so; do
+CHMC_HIP_LIBRARY=$R/manifold_mcmc_for_diffusions_amd/$lib python bench.py --no-cpu-baseline > gpurun_out/r02u/b_$lib.$i.json 2>/dev/null
+python - $lib $i <<'PY'
+import json,sys
+lib,i=sys.argv[1:]
+d=json.loads(open(f'gpurun_out/r02u/b_{lib}.{i}.json').read().strip().splitlines()[-1])
+t=d['config']['kernel_classes_warmup']
+print(lib,i,round(d['value']),round(d['ms_per_step'],3),'newton_blk',t['newton_blk']['ms_per_step'])
+PY
+done; done
+CHMC_HIP_LIBRARY=$R/manifold_mcmc_for_diffusions_amd/libchmc_hip_w3z.so python -m pytest tests/test_hip_parity.py tests/test_golden.py -m gpu -x -q -k "not sir" 2>&1 | tail -2
