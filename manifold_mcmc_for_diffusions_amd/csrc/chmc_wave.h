@@ -110,6 +110,49 @@ __device__ __forceinline__ void dpp_prefix_products(const double* A, double* P, 
   }
 }
 
+// One DPP step of an inclusive AFFINE prefix scan: every lane holds the map x -> P x + e_i (NE vectors e_i of length X
+// share the matrix P); the step composes the lane's accumulated map AFTER the map fetched from a lower lane,
+//     P <- P Pl,   e_i <- P el_i + e_i.
+// Lanes without a source receive the identity map (Pl = I, el = 0), so the step is unconditional.  srcP / srce: the
+// values that are shifted (the ORIGINAL maps in the row_shr 1 / 2 / 3 steps, the accumulated ones afterwards).
+template <int X, int NE, int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ void dpp_affine_step(double* P, double* e, const double* srcP, const double* srce) {
+  double Pl[X * X], Pn[X * X];
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) Pl[i] = dpp_mov<CTRL, ROW_MASK, BANK_MASK>(srcP[i], (i / X == i % X) ? 1.0 : 0.0);
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    double el[X];
+#pragma unroll
+    for (int d = 0; d < X; ++d) el[d] = dpp_mov<CTRL, ROW_MASK, BANK_MASK>(srce[i * X + d], 0.0);
+#pragma unroll
+    for (int a = 0; a < X; ++a) {
+      double tt = e[i * X + a];
+#pragma unroll
+      for (int d = 0; d < X; ++d) tt += P[a * X + d] * el[d];
+      e[i * X + a] = tt;
+    }
+  }
+  matmul_xx<X>(P, Pl, Pn);
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) P[i] = Pn[i];
+}
+template <int X, int NE>
+__device__ __forceinline__ void dpp_affine_prefix(double* P, double* e) {
+  double P0[X * X], e0[NE * X];
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) P0[i] = P[i];
+#pragma unroll
+  for (int i = 0; i < NE * X; ++i) e0[i] = e[i];
+  dpp_affine_step<X, NE, 0x111, 0xf, 0xf>(P, e, P0, e0);  // row_shr:1 of the ORIGINAL maps
+  dpp_affine_step<X, NE, 0x112, 0xf, 0xf>(P, e, P0, e0);  // row_shr:2
+  dpp_affine_step<X, NE, 0x113, 0xf, 0xf>(P, e, P0, e0);  // row_shr:3
+  dpp_affine_step<X, NE, 0x114, 0xf, 0xe>(P, e, P, e);    // row_shr:4, banks 1-3
+  dpp_affine_step<X, NE, 0x118, 0xf, 0xc>(P, e, P, e);    // row_shr:8, banks 2-3
+  dpp_affine_step<X, NE, 0x142, 0xa, 0xf>(P, e, P, e);    // row_bcast:15, rows 1 and 3
+  dpp_affine_step<X, NE, 0x143, 0xc, 0xf>(P, e, P, e);    // row_bcast:31, rows 2 and 3
+}
+
 // MODE 0: state evaluation -- store dc/dv rows, symmetric Gram, dc/du rows into the slot.
 // MODE 1: Newton iteration -- Gram of the iterate's rows against the stored rows of slot `which`.
 // GRAM false (16-row blocks): no Gram accumulation -- the rows are stored (MODE 0: into the slot, MODE 1: into
@@ -1554,26 +1597,30 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
         }
       }
       // inclusive affine prefix scan: (P, e)_l maps the tangents at the tile start to those after step l
+      if constexpr (RM <= 8) {
+        dpp_affine_prefix<X, RM>(P, e);  // DPP path of the vector ALU (the shuffle version below waits on the LDS crossbar)
+      } else {
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        double Pp[X * X], ep[RM * X], Pn[X * X];
+        for (int o = 1; o < 64; o <<= 1) {
+          double Pp[X * X], ep[RM * X], Pn[X * X];
 #pragma unroll
-        for (int i = 0; i < X * X; ++i) Pp[i] = __shfl_up(P[i], o, 64);
+          for (int i = 0; i < X * X; ++i) Pp[i] = __shfl_up(P[i], o, 64);
 #pragma unroll URM
-        for (int i = 0; i < RM * X; ++i) ep[i] = __shfl_up(e[i], o, 64);
-        if (lane >= o) {
+          for (int i = 0; i < RM * X; ++i) ep[i] = __shfl_up(e[i], o, 64);
+          if (lane >= o) {
 #pragma unroll URM
-          for (int i = 0; i < RM; ++i)
+            for (int i = 0; i < RM; ++i)
 #pragma unroll
-            for (int a = 0; a < X; ++a) {
-              double tt = e[i * X + a];
+              for (int a = 0; a < X; ++a) {
+                double tt = e[i * X + a];
 #pragma unroll
-              for (int d = 0; d < X; ++d) tt += P[a * X + d] * ep[i * X + d];
-              e[i * X + a] = tt;
-            }
-          matmul_xx<X>(P, Pp, Pn);
+                for (int d = 0; d < X; ++d) tt += P[a * X + d] * ep[i * X + d];
+                e[i * X + a] = tt;
+              }
+            matmul_xx<X>(P, Pp, Pn);
 #pragma unroll
-          for (int i = 0; i < X * X; ++i) P[i] = Pn[i];
+            for (int i = 0; i < X * X; ++i) P[i] = Pn[i];
+          }
         }
       }
       // exclusive values: tangents AT this lane's step
@@ -1582,17 +1629,10 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
 #pragma unroll URM
         for (int i = 0; i < RM; ++i)
 #pragma unroll
-          for (int a = 0; a < X; ++a) {
-            double eex = __shfl_up(e[i * X + a], 1, 64);
-            double tt = lane == 0 ? 0.0 : eex;
-            xs[i * X + a] = tt;
-          }
+          for (int a = 0; a < X; ++a) xs[i * X + a] = dpp_mov<0x138, 0xf, 0xf>(e[i * X + a], 0.0);  // wave_shr:1
         double Pex[X * X];
 #pragma unroll
-        for (int i = 0; i < X * X; ++i) {
-          const double y = __shfl_up(P[i], 1, 64);
-          Pex[i] = lane == 0 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
-        }
+        for (int i = 0; i < X * X; ++i) Pex[i] = dpp_mov<0x138, 0xf, 0xf>(P[i], (i / X == i % X) ? 1.0 : 0.0);
 #pragma unroll URM
         for (int i = 0; i < RM; ++i)
 #pragma unroll
@@ -1615,12 +1655,12 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
       {
         double P6[X * X], nx[RM * X];
 #pragma unroll
-        for (int i = 0; i < X * X; ++i) P6[i] = __shfl(P[i], 63, 64);
+        for (int i = 0; i < X * X; ++i) P6[i] = bcast_lane63(P[i]);
 #pragma unroll URM
         for (int i = 0; i < RM; ++i)
 #pragma unroll
           for (int a = 0; a < X; ++a) {
-            double tt = __shfl(e[i * X + a], 63, 64);
+            double tt = bcast_lane63(e[i * X + a]);
 #pragma unroll
             for (int d = 0; d < X; ++d) tt += P6[a * X + d] * xdc[i * X + d];
             nx[i * X + a] = tt;

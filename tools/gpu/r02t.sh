@@ -1,6 +1,6 @@
 R=$PWD
 mkdir -p gpurun_out/r02t
-python -m pytest tests/test_hip_parity.py tests/test_golden.py -m gpu -x -q -k "not sir" 2>&1 | tail -3
+python -m pytest tests/test_hip_parity.py tests/test_golden.py -m gpu -x -q -k "not halves" 2>&1 | tail -3
 for i in 1 2; do for lib in libchmc_hip.so libchmc_hip_prev.so; do
 CHMC_HIP_LIBRARY=$R/manifold_mcmc_for_diffusions_amd/$lib python bench.py --no-cpu-baseline > gpurun_out/r02t/b_$lib.$i.json 2>/dev/null
 python - $lib $i <<'PY'
@@ -8,6 +8,6 @@ import json,sys
 lib,i=sys.argv[1:]
 d=json.loads(open(f'gpurun_out/r02t/b_{lib}.{i}.json').read().strip().splitlines()[-1])
 t=d['config']['kernel_classes_warmup']
-print(lib,i,round(d['value']),round(d['ms_per_step'],3),'newton_blk',t['newton_blk']['ms_per_step'],'k',round(d['config']['mean_newton_iters_fwd_plus_bwd'],4))
+print(lib,i,round(d['value']),round(d['ms_per_step'],3),'gld',t['grad_log_det_blk']['ms_per_step'],'state',t['state_blk']['ms_per_step'],'newton',t['newton_blk']['ms_per_step'])
 PY
 done; done
