@@ -153,6 +153,43 @@ __device__ __forceinline__ void dpp_affine_prefix(double* P, double* e) {
   dpp_affine_step<X, NE, 0x143, 0xc, 0xf>(P, e, P, e);    // row_bcast:31, rows 2 and 3
 }
 
+// Joint prefix scan of (matrix, row vector) pairs for the recurrence  xbar <- xbar A + h  (later steps in lower lanes):
+// every lane holds the map  xbar -> xbar I2 + g;  a step composes the map of the LATER steps (lower lanes) first,
+//     g <- gl I2 + g,   I2 <- Yl I2.        Lanes without a source receive the identity map (Yl = I, gl = 0).
+template <int X, int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ void dpp_rowaffine_step(double* I2, double* g, const double* srcI, const double* srcg) {
+  double Yl[X * X], gl[X], Pn[X * X];
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) Yl[i] = dpp_mov<CTRL, ROW_MASK, BANK_MASK>(srcI[i], (i / X == i % X) ? 1.0 : 0.0);
+#pragma unroll
+  for (int a = 0; a < X; ++a) gl[a] = dpp_mov<CTRL, ROW_MASK, BANK_MASK>(srcg[a], 0.0);
+#pragma unroll
+  for (int d = 0; d < X; ++d) {
+    double tt = g[d];
+#pragma unroll
+    for (int a = 0; a < X; ++a) tt += gl[a] * I2[a * X + d];
+    g[d] = tt;
+  }
+  matmul_xx<X>(Yl, I2, Pn);
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) I2[i] = Pn[i];
+}
+template <int X>
+__device__ __forceinline__ void dpp_rowaffine_prefix(double* I2, double* g) {
+  double I0_[X * X], g0_[X];
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) I0_[i] = I2[i];
+#pragma unroll
+  for (int a = 0; a < X; ++a) g0_[a] = g[a];
+  dpp_rowaffine_step<X, 0x111, 0xf, 0xf>(I2, g, I0_, g0_);
+  dpp_rowaffine_step<X, 0x112, 0xf, 0xf>(I2, g, I0_, g0_);
+  dpp_rowaffine_step<X, 0x113, 0xf, 0xf>(I2, g, I0_, g0_);
+  dpp_rowaffine_step<X, 0x114, 0xf, 0xe>(I2, g, I2, g);
+  dpp_rowaffine_step<X, 0x118, 0xf, 0xc>(I2, g, I2, g);
+  dpp_rowaffine_step<X, 0x142, 0xa, 0xf>(I2, g, I2, g);
+  dpp_rowaffine_step<X, 0x143, 0xc, 0xf>(I2, g, I2, g);
+}
+
 // MODE 0: state evaluation -- store dc/dv rows, symmetric Gram, dc/du rows into the slot.
 // MODE 1: Newton iteration -- Gram of the iterate's rows against the stored rows of slot `which`.
 // GRAM false (16-row blocks): no Gram accumulation -- the rows are stored (MODE 0: into the slot, MODE 1: into
@@ -1746,7 +1783,7 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
           if (i == bd.ny + a) Lam[i * X + a] = 1.0;
     }
     for (int t = ntile - 1; t >= 0; --t) {
-      const int off = (t << 6) + lane;
+      const int off = (t << 6) + (63 - lane);  // LATER steps in LOWER lanes: the suffix scans become DPP prefix scans
       const bool valid = off < S;
       const int s = j * S + off;
       const size_t col = colb + (size_t)s * V;
@@ -1769,27 +1806,9 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
 #pragma unroll
         for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
       }
-      // matrix suffix scan (adjoint rows)
-      double Inc[X * X];
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        double Y[X * X], Pn[X * X];
-#pragma unroll
-        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o, 64);
-        matmul_xx<X>(Y, Inc, Pn);
-        if (lane + o < 64) {
-#pragma unroll
-          for (int i = 0; i < X * X; ++i) Inc[i] = Pn[i];
-        }
-      }
-      double E[X * X];
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) {
-        const double y = __shfl_down(Inc[i], 1, 64);
-        E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
-      }
+      // products of the transition matrices of the later steps (adjoint rows): exclusive prefix products over the lanes
+      double Inc[X * X], E[X * X];
+      dpp_prefix_products<X>(A, Inc, E);
       // Hessian contraction source of this step
       double H[NXI];
       {
@@ -1841,31 +1860,11 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
       for (int i = 0; i < X * X; ++i) I2[i] = A[i];
 #pragma unroll
       for (int a = 0; a < X; ++a) gi[a] = H[a];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        double Y[X * X], gp[X], Pn[X * X];
-#pragma unroll
-        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(I2[i], o, 64);
-#pragma unroll
-        for (int a = 0; a < X; ++a) gp[a] = __shfl_down(gi[a], o, 64);
-        if (lane + o < 64) {
-#pragma unroll
-          for (int d = 0; d < X; ++d) {
-            double tt = gi[d];
-#pragma unroll
-            for (int a = 0; a < X; ++a) tt += gp[a] * I2[a * X + d];
-            gi[d] = tt;
-          }
-          matmul_xx<X>(Y, I2, Pn);
-#pragma unroll
-          for (int i = 0; i < X * X; ++i) I2[i] = Pn[i];
-        }
-      }
+      dpp_rowaffine_prefix<X>(I2, gi);
       double xbs[X];  // x-bar at the state after this lane's step
 #pragma unroll
       for (int d = 0; d < X; ++d) {
-        const double ge = __shfl_down(gi[d], 1, 64);
-        double tt = lane == 63 ? 0.0 : ge;
+        double tt = dpp_mov<0x138, 0xf, 0xf>(gi[d], 0.0);  // wave_shr:1: the sources of the later steps
 #pragma unroll
         for (int a = 0; a < X; ++a) tt += xb[a] * E[a * X + d];
         xbs[d] = tt;
@@ -1889,9 +1888,9 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
       // carries
       double I0[X * X], g0[X];
 #pragma unroll
-      for (int i = 0; i < X * X; ++i) I0[i] = bcast0(I2[i]);
+      for (int i = 0; i < X * X; ++i) I0[i] = bcast_lane63(I2[i]);
 #pragma unroll
-      for (int a = 0; a < X; ++a) g0[a] = bcast0(gi[a]);
+      for (int a = 0; a < X; ++a) g0[a] = bcast_lane63(gi[a]);
       {
         double nb[X];
 #pragma unroll
@@ -2029,7 +2028,7 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave_ldsrows(Sys sy, Slots sl, 
     }
     lds_sync();
     for (int t = ntile - 1; t >= 0; --t) {
-      const int off = (t << 6) + lane;
+      const int off = (t << 6) + (63 - lane);  // LATER steps in LOWER lanes: the suffix scans become DPP prefix scans
       const bool valid = off < S;
       const int s = j * S + off;
       const size_t col = colb + (size_t)s * V;
@@ -2052,27 +2051,9 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave_ldsrows(Sys sy, Slots sl, 
 #pragma unroll
         for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
       }
-      // matrix suffix scan (adjoint rows)
-      double Inc[X * X];
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        double Y[X * X], Pn[X * X];
-#pragma unroll
-        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o, 64);
-        matmul_xx<X>(Y, Inc, Pn);
-        if (lane + o < 64) {
-#pragma unroll
-          for (int i = 0; i < X * X; ++i) Inc[i] = Pn[i];
-        }
-      }
-      double E[X * X];
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) {
-        const double y = __shfl_down(Inc[i], 1, 64);
-        E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
-      }
+      // products of the transition matrices of the later steps (adjoint rows): exclusive prefix products over the lanes
+      double Inc[X * X], E[X * X];
+      dpp_prefix_products<X>(A, Inc, E);
       // Hessian contraction source of this step
       double H[NXI];
       {
@@ -2124,31 +2105,11 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave_ldsrows(Sys sy, Slots sl, 
       for (int i = 0; i < X * X; ++i) I2[i] = A[i];
 #pragma unroll
       for (int a = 0; a < X; ++a) gi[a] = H[a];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        double Y[X * X], gp[X], Pn[X * X];
-#pragma unroll
-        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(I2[i], o, 64);
-#pragma unroll
-        for (int a = 0; a < X; ++a) gp[a] = __shfl_down(gi[a], o, 64);
-        if (lane + o < 64) {
-#pragma unroll
-          for (int d = 0; d < X; ++d) {
-            double tt = gi[d];
-#pragma unroll
-            for (int a = 0; a < X; ++a) tt += gp[a] * I2[a * X + d];
-            gi[d] = tt;
-          }
-          matmul_xx<X>(Y, I2, Pn);
-#pragma unroll
-          for (int i = 0; i < X * X; ++i) I2[i] = Pn[i];
-        }
-      }
+      dpp_rowaffine_prefix<X>(I2, gi);
       double xbs[X];  // x-bar at the state after this lane's step
 #pragma unroll
       for (int d = 0; d < X; ++d) {
-        const double ge = __shfl_down(gi[d], 1, 64);
-        double tt = lane == 63 ? 0.0 : ge;
+        double tt = dpp_mov<0x138, 0xf, 0xf>(gi[d], 0.0);  // wave_shr:1: the sources of the later steps
 #pragma unroll
         for (int a = 0; a < X; ++a) tt += xb[a] * E[a * X + d];
         xbs[d] = tt;
@@ -2172,9 +2133,9 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave_ldsrows(Sys sy, Slots sl, 
       // carries
       double I0[X * X], g0[X];
 #pragma unroll
-      for (int i = 0; i < X * X; ++i) I0[i] = bcast0(I2[i]);
+      for (int i = 0; i < X * X; ++i) I0[i] = bcast_lane63(I2[i]);
 #pragma unroll
-      for (int a = 0; a < X; ++a) g0[a] = bcast0(gi[a]);
+      for (int a = 0; a < X; ++a) g0[a] = bcast_lane63(gi[a]);
       {
         double nb[X];
 #pragma unroll
