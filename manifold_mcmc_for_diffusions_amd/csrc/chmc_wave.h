@@ -342,7 +342,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   };
   auto fetch = [&](int tt, Raw& r) {
     const int jj = tt / ntile, t = tt - jj * ntile;
-    const int off = (t << 6) + lane;
+    const int off = (t << 6) + (63 - lane);  // later steps in lower lanes (DPP prefix scans)
     r.valid = tt >= 0 && off < S;
     r.s = jj * S + off;
     if (r.valid) {
@@ -384,25 +384,12 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
       for (int i = 0; i < X * Z; ++i) o.Zf[i] = 0.0;
     }
     // inclusive suffix scan: Inc_l = A_{hi} ... A_{l}  (later steps on the left)
-    double Inc[X * X];
+    double Inc[X * X], Eex[X * X];  // inclusive / exclusive products of the later steps (lower lanes)
+    dpp_prefix_products<X>(A, Inc, Eex);
 #pragma unroll
-    for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
-#pragma unroll
-    for (int o2 = 1; o2 < 64; o2 <<= 1) {
-      double Y[X * X], P[X * X];
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o2, 64);
-      matmul_xx<X>(Y, Inc, P);
-      if (lane + o2 < 64) {
-#pragma unroll
-        for (int i = 0; i < X * X; ++i) Inc[i] = P[i];
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < X * X; ++i) {  // exclusive: product over the later lanes only
-      const double y = __shfl_down(Inc[i], 1, 64);
-      o.E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
-      o.I0[i] = bcast0(Inc[i]);  // lane 0's inclusive product carries the rows across the tile
+    for (int i = 0; i < X * X; ++i) {
+      o.E[i] = Eex[i];
+      o.I0[i] = bcast_lane63(Inc[i]);  // the whole tile's product carries the rows across the tile
     }
   };
   auto stage2 = [&](const Scan& sc, const Raw& r, const Rows& rw) {
@@ -991,7 +978,7 @@ __global__ void __launch_bounds__(64) k_rev_wave_ldsrows(Sys sy, Slots sl, Work 
   };
   auto fetch = [&](int tt, Raw& r) {
     const int jj = tt / ntile, t = tt - jj * ntile;
-    const int off = (t << 6) + lane;
+    const int off = (t << 6) + (63 - lane);  // later steps in lower lanes (DPP prefix scans)
     r.valid = tt >= 0 && off < S;
     r.s = jj * S + off;
 #pragma unroll
@@ -1028,26 +1015,13 @@ __global__ void __launch_bounds__(64) k_rev_wave_ldsrows(Sys sy, Slots sl, Work 
 #pragma unroll
       for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
     }
-    double Inc[X * X];  // inclusive suffix products (later steps on the left)
-#pragma unroll
-    for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      double Y[X * X], P[X * X];
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o, 64);
-      matmul_xx<X>(Y, Inc, P);
-      if (lane + o < 64) {
-#pragma unroll
-        for (int i = 0; i < X * X; ++i) Inc[i] = P[i];
-      }
-    }
+    double Inc[X * X], Eex[X * X];  // inclusive / exclusive products of the later steps (lower lanes)
+    dpp_prefix_products<X>(A, Inc, Eex);
     double E[X * X], I0[X * X];
 #pragma unroll
     for (int i = 0; i < X * X; ++i) {
-      const double y = __shfl_down(Inc[i], 1, 64);
-      E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : y;
-      I0[i] = bcast0(Inc[i]);
+      E[i] = Eex[i];
+      I0[i] = bcast_lane63(Inc[i]);
     }
     const size_t col = colb + (size_t)r0.s * V;
 #pragma unroll 1
@@ -1301,7 +1275,7 @@ __global__ void __launch_bounds__(256) k_nld_grad_wave(Sys sy, const double* qin
       for (int a = 0; a < X; ++a) Lam[a] += wj * og[a];
     }
     for (int t = ntile - 1; t >= 0; --t) {
-      const int off = (t << 6) + lane;
+      const int off = (t << 6) + (63 - lane);  // later steps in lower lanes (DPP prefix scans)
       const bool valid = off < S;
       const int s = j * S + off;
       double A[X * X], Bm[X * V], Zf[X * Z], vv[V];
@@ -1322,26 +1296,13 @@ __global__ void __launch_bounds__(256) k_nld_grad_wave(Sys sy, const double* qin
 #pragma unroll
         for (int a = 0; a < V; ++a) vv[a] = 0.0;
       }
-      double Inc[X * X];
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) Inc[i] = A[i];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {  // inclusive suffix products (later steps on the left)
-        double Y[X * X], P[X * X];
-#pragma unroll
-        for (int i = 0; i < X * X; ++i) Y[i] = __shfl_down(Inc[i], o, 64);
-        matmul_xx<X>(Y, Inc, P);
-        if (lane + o < 64) {
-#pragma unroll
-          for (int i = 0; i < X * X; ++i) Inc[i] = P[i];
-        }
-      }
+      double Inc[X * X], Eex[X * X];  // inclusive / exclusive products of the later steps (lower lanes)
+      dpp_prefix_products<X>(A, Inc, Eex);
       double E[X * X], I0[X * X];
 #pragma unroll
       for (int i = 0; i < X * X; ++i) {
-        const double yv = __shfl_down(Inc[i], 1, 64);
-        E[i] = lane == 63 ? ((i / X == i % X) ? 1.0 : 0.0) : yv;
-        I0[i] = bcast0(Inc[i]);
+        E[i] = Eex[i];
+        I0[i] = bcast_lane63(Inc[i]);
       }
       double Ls[X];
 #pragma unroll
