@@ -102,12 +102,17 @@ def run(num_chains=64, n_iter=700, n_warm=200, n_step=24, out_dir=None, seed=202
     # the pilot missed (healthy chains move in 80-100 % of their transitions, stuck ones in 0-3 %); chains that moved in
     # fewer than 10 % of the main transitions are left out of the summary and counted.
     tr = {k: np.load(f) for k, f in res["trace_files"].items()}
-    moving = (np.diff(tr["σ"][:, n_warm:], axis=1) != 0).mean(1) >= 0.1
+    moved = np.diff(tr["σ"][:, n_warm:], axis=1) != 0
+    moving = moved.mean(1) >= 0.1
+    # ... and a chain that is released from such a start only during the main phase (moving in less than half of the
+    # transitions of some 50-transition window, then travelling to the bulk) is still in its transient: left out as well
+    nwin = max(moved.shape[1] // 50, 1)
+    moving &= np.array([w.mean(1) for w in np.array_split(moved, nwin, axis=1)]).min(0) >= 0.5
     sm = summarize({k: v[moving][:, n_warm:] for k, v in tr.items()})
     if verbose and not moving.all():
         # diagnosis of the chains left out: where their parameters sit and how their transitions ended
         sm_all = summarize({k: v[:, n_warm:] for k, v in tr.items()})
-        print("chains left out of the summary (moved in < 10 % of the main transitions):")
+        print("chains left out of the summary (moved in < 10 % of the main transitions, or in < 50 % of some window of 50):")
         oc = res.get("chain_outcomes")
         for c in np.flatnonzero(~moving):
             line = f"  chain {c:3d}: sigma {tr['σ'][c, -1]:.3f} eps {tr['ϵ'][c, -1]:.4f} gamma {tr['γ'][c, -1]:.3f} beta {tr['β'][c, -1]:.3f}"

@@ -17,13 +17,16 @@ import pandas as pd
 SO = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "manifold_mcmc_for_diffusions_amd",
                   "libchmc_hip.so")
 
-CLASS_OF = [  # substring of the kernel name -> profiling class of include/chmc.h
+CLASS_OF = [  # substring of the kernel name -> profiling class of include/chmc.h (first match wins)
+    ("k_newton_lean", "newton_blk"), ("k_newton_factor_wave", "sym_blk"), ("k_gram_rows", "newton_blk"),
+    ("k_rev_wave_ldsrows<chmc::SirModel, 16, 1", "newton_blk"), ("k_rev_wave_ldsrows<chmc::SirVsModel, 16, 1", "newton_blk"),
+    ("k_rev_wave_ldsrows", "state_blk"),
     ("k_rev_wave<chmc::FhnModel, 7, 1", "newton_blk"), ("k_rev_wave<chmc::FhnModel, 7, 0", "state_blk"),
     ("k_rev_wave<chmc::FhnModel, 6, 1", "newton_blk"), ("k_rev_wave<chmc::FhnModel, 6, 0", "state_blk"),
     ("k_rev_wave<chmc::SirModel, 16, 1", "newton_blk"), ("k_rev_wave<chmc::SirModel, 16, 0", "state_blk"),
-    ("k_gram_rows", "newton_blk"),
     ("k_gld_", "grad_log_det_blk"), ("KGldPrep", "sym_blk"), ("KUpdate", "update"), ("k_solve_chain_wave", "solve_chain"),
-    ("k_jw_wave", "jacob_vec"), ("KFwd", "constr"), ("k_fwd_scan", "constr"), ("KKick", "elementwise"), ("KFlow", "elementwise"),
+    ("k_jw_wave", "jacob_vec"), ("KFwd", "constr"), ("k_fwd_scan", "constr"), ("k_fwd_par", "constr"),
+    ("KKick", "elementwise"), ("KFlow", "elementwise"),
     ("KMomFix", "elementwise"), ("KRevDiff", "elementwise"), ("Factor", "sym_blk"), ("KSymBlk", "sym_blk"),
 ]
 
