@@ -91,16 +91,27 @@ int chmc_set_metric(chmc_ctx* ctx, const double* M_0);
 /* One leaf of a batched dynamic-integration (no-U-turn) tree (the caller of integrator.step in the reference:
  * mici.transitions.MultinomialDynamicIntegrationTransition, scripts/utils.py:292-301), fused into one pass over the state
  * the last chmc_leapfrog_step produced.  The tree vectors stay with the caller as device buffers (plain pointers:
- * sub_prop_q, sub_sum [B][Q]; ck_p, ck_sum [D][B][Q]).  For every chain with run[c] != 0:
+ * sub_prop_q, sub_sum [B][Q]; ck_p, ck_sum, ck_end [D][B][Q]).  For every chain with run[c] != 0:
  *   sub_sum += mom;  sub_prop_q = pos if take[c];  ck_p[store_slot], ck_sum[store_slot] = mom, sub_sum (store_slot >= 0);
- *   out[c][2k], out[c][2k + 1] = dh_dmom(ck_p[check_lo + k]) . span_k, dh_dmom(mom) . span_k for k < n_check, with
- *   span_k = sub_sum - ck_sum[check_lo + k] + ck_p[check_lo + k]: the two sides of the no-U-turn criterion on the span
- *   of leaves from checkpoint check_lo + k to this one (dh_dmom = metric.inv @ mom :1204-1208).
- * out is [B][2 n_check] on the host (zeros for chains that did not run; may be NULL when n_check == 0); n_check <= 10.
+ * and for the n_check nested sub-tree spans that end at this leaf (span k starts at the leaf recorded in checkpoint
+ * check_lo + k; slot check_lo holds the largest span, and the span of slot check_lo + k + 1 is the right half of span k):
+ *   out[c][6k], out[c][6k + 1] = dh_dmom(ck_p[check_lo + k]) . rho, dh_dmom(mom) . rho with rho = sub_sum -
+ *   ck_sum[check_lo + k] + ck_p[check_lo + k] (momentum sum of the span): the two sides of the no-U-turn criterion
+ *   (dh_dmom = metric.inv @ mom :1204-1208);
+ *   with ck_end != NULL, for k < n_check - 1 (spans of four leaves or more), Mici's additional sub-tree checks
+ *   (do_extra_subtree_checks, the transition's default) across the two halves of the span -- first leaf a, last leaf m
+ *   of the left half, first leaf m + 1 of the right half, this leaf b:
+ *   out[c][6k + 2], out[c][6k + 3] = dh_dmom(p_a) . rho1, dh_dmom(p_{m+1}) . rho1, rho1 = momenta of a..m plus p_{m+1};
+ *   out[c][6k + 4], out[c][6k + 5] = dh_dmom(p_m) . rho2, dh_dmom(p_b) . rho2,     rho2 = momenta of m+1..b plus p_m;
+ *   afterwards ck_end[check_lo] = mom (this leaf ends the left half of the next larger span starting at slot check_lo).
+ *   Entries that are not computed are 0.
+ * out is [B][6 n_check] on the host (zeros for chains that did not run; may be NULL when n_check == 0); n_check <= 10.
  * Sums are formed in a fixed order (no atomics).  run / take are host arrays (take is decided by the caller from
- * chmc_hamiltonian of the same state: multinomial sampling of the sub-tree's proposal). */
+ * chmc_hamiltonian of the same state: multinomial sampling of the sub-tree's proposal); chmc_tree_step is the variant
+ * that takes these decisions on the device. */
 int chmc_tree_leaf(chmc_ctx* ctx, const int* run, const int* take, void* sub_prop_q_dev, void* sub_sum_dev,
-                   void* ck_p_dev, void* ck_sum_dev, int store_slot, int check_lo, int n_check, double* out);
+                   void* ck_p_dev, void* ck_sum_dev, void* ck_end_dev, int store_slot, int check_lo, int n_check,
+                   double* out);
 int chmc_set_momentum(chmc_ctx* ctx, const double* p);
 int chmc_get_state_device(chmc_ctx* ctx, void* q_dev, void* p_dev);  /* device-to-device copies */
 int chmc_set_momentum_device(chmc_ctx* ctx, const void* p_dev);

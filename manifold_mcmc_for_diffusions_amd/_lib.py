@@ -38,8 +38,8 @@ SYMBOLS = [
     ("chmc_get_state", C.c_int, [C.c_void_p, dp, dp, dp, ip]),
     ("chmc_init_linear_interpolation", C.c_int, [C.c_void_p, dp, dp, dp, C.c_int]),
     ("chmc_set_metric", C.c_int, [C.c_void_p, dp]),
-    ("chmc_tree_leaf", C.c_int, [C.c_void_p, ip, ip, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int,
-                                 C.c_int, dp]),
+    ("chmc_tree_leaf", C.c_int, [C.c_void_p, ip, ip, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_int, C.c_int, dp]),
     ("chmc_set_momentum", C.c_int, [C.c_void_p, dp]),
     ("chmc_get_state_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("chmc_set_momentum_device", C.c_int, [C.c_void_p, C.c_void_p]),

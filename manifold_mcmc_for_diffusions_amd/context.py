@@ -109,15 +109,18 @@ class ChmcContext:
         check(self.L.chmc_set_metric(self.h, ptr(m)), "chmc_set_metric")
         self.M_0 = m.copy()
 
-    def tree_leaf(self, run, take, sub_prop_q_ptr, sub_sum_ptr, ck_p_ptr, ck_sum_ptr, store_slot, check_lo, n_check):
+    def tree_leaf(self, run, take, sub_prop_q_ptr, sub_sum_ptr, ck_p_ptr, ck_sum_ptr, store_slot, check_lo, n_check,
+                  ck_end_ptr=None):
         """Fused bookkeeping of one leaf of the batched dynamic-integration trees (chmc_tree_leaf, include/chmc.h):
-        returns [B, 2 n_check] = the two no-U-turn criterion values per checked span."""
-        out = np.zeros((self.B, 2 * n_check))
+        returns [B, n_check, 6] = per checked span the two no-U-turn criterion values and, with `ck_end_ptr`, the four
+        values of Mici's additional sub-tree checks (zeros where not computed)."""
+        out = np.zeros((self.B, n_check, 6))
         r = np.ascontiguousarray(run, dtype=np.int32)
         t = np.ascontiguousarray(take, dtype=np.int32)
         check(self.L.chmc_tree_leaf(self.h, iptr(r), iptr(t), C.c_void_p(sub_prop_q_ptr), C.c_void_p(sub_sum_ptr),
-                                    C.c_void_p(ck_p_ptr), C.c_void_p(ck_sum_ptr), int(store_slot), int(check_lo),
-                                    int(n_check), ptr(out) if n_check else None), "chmc_tree_leaf")
+                                    C.c_void_p(ck_p_ptr), C.c_void_p(ck_sum_ptr), C.c_void_p(ck_end_ptr or 0),
+                                    int(store_slot), int(check_lo), int(n_check), ptr(out) if n_check else None),
+              "chmc_tree_leaf")
         return out
 
     def set_momentum(self, p):

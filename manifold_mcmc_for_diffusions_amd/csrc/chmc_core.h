@@ -1932,10 +1932,19 @@ struct KCommitInner {
 // One leaf of a dynamic (no-U-turn) trajectory tree, batched: everything the caller's tree bookkeeping needs from the
 // state the integrator has just produced, in ONE pass over its position and momentum (see chmc_tree_leaf in
 // include/chmc.h).  Row-sum launch: f(c, col, acc) handles components col, col + 1 of chain c and adds into the
-// per-item accumulators: acc[2k] += dh_dmom(ck_p[lo + k]) . span_k, acc[2k + 1] += dh_dmom(p) . span_k with span_k = sub_sum - ck_sum[lo + k] + ck_p[lo + k] (momentum sum of the leaves
-// from checkpoint lo + k to this one), dh_dmom = metric.inv @ mom (:1204-1208).
+// per-item accumulators.  The sub-tree spans that end at this (odd) leaf b are nested; span k starts at the leaf a_k
+// recorded in checkpoint slot lo + k (slot lo: the largest span) and the span of slot lo + k + 1 is its right half.
+// With v(.) = dh_dmom = metric.inv @ mom (:1204-1208) and S = the momentum sum of the sub-tree's leaves up to b:
+//   acc[6k + 0], acc[6k + 1] = v(p_a) . rho, v(p_b) . rho,   rho = sum of the momenta of leaves a .. b
+//                                                           (= S - ck_sum[a] + ck_p[a]);
+// and, when `ck_end` is given (Mici's additional sub-tree checks across the two halves of a span of >= 4 leaves,
+// m = last leaf of the left half, m + 1 = first leaf of the right half, both known from the checkpoints):
+//   acc[6k + 2], acc[6k + 3] = v(p_a) . rho1, v(p_{m+1}) . rho1,   rho1 = (momenta of a .. m) + p_{m+1}
+//   acc[6k + 4], acc[6k + 5] = v(p_m) . rho2, v(p_b) . rho2,       rho2 = (momenta of m+1 .. b) + p_m.
+// After the checks the leaf's momentum is recorded in ck_end[lo]: b is the last leaf of the left half of the next
+// larger span that starts at a_lo.
 #define CHMC_TREE_MAXCHK 10
-#define CHMC_ROWSUM_MAX (2 * CHMC_TREE_MAXCHK)
+#define CHMC_ROWSUM_MAX (6 * CHMC_TREE_MAXCHK)
 struct KTreeLeaf {
   Sys sy;
   Slots sl;
@@ -1945,8 +1954,17 @@ struct KTreeLeaf {
   double* sub_sum;     // [B][Q] momentum sum of the sub-tree's leaves so far
   double* ck_p;        // [D][B][Q] momentum at the first leaf of a pending span
   double* ck_sum;      // [D][B][Q] sub_sum at that leaf
+  double* ck_end;      // [D][B][Q] momentum at the last leaf of the left half of the pending span of a slot (or null)
   int store, lo, nchk;  // store: checkpoint slot this leaf is recorded in (-1: none); checks against slots lo .. lo + nchk - 1
   CHMC_HD bool active(int c) const { return run[c] != 0; }
+  CHMC_HD double2_ vel(const double* base, size_t cq, int col, double2_ p) const {
+    // metric.inv @ p: only the u-part of the block metric differs from p
+    if (sy.m0 && col < sy.U) {
+      p.x = metric_inv_u(sy, base + cq, col);
+      if (col + 1 < sy.U) p.y = metric_inv_u(sy, base + cq, col + 1);
+    }
+    return p;
+  }
   CHMC_HD void operator()(int c, int col, double* acc) const {
     const int s = sl.cur[c];
     const size_t cq = (size_t)c * sy.Q, i = cq + col, BQ = (size_t)sy.B * sy.Q;
@@ -1960,37 +1978,55 @@ struct KTreeLeaf {
       stv2(ck_p + store * BQ + i, p, wide, two);
       stv2(ck_sum + store * BQ + i, S, wide, two);
     }
-    // velocity of this leaf (metric.inv @ p: only the u-part of the block metric differs from p)
-    double2_ vp = p;
-    const bool inu = sy.m0 && col < sy.U;
-    if (inu) {
-      vp.x = metric_inv_u(sy, pick(sl.p, s) + cq, col);
-      if (col + 1 < sy.U) vp.y = metric_inv_u(sy, pick(sl.p, s) + cq, col + 1);
-    }
+    const double2_ vp = vel(pick(sl.p, s), cq, col, p);
+    double2_ a_r, cs_r;  // checkpoint of the right half (the next smaller span), carried from slot to slot
+    a_r.x = a_r.y = cs_r.x = cs_r.y = 0.0;
+    // from the smallest span (slot lo + nchk - 1) to the largest (slot lo)
     CHMC_UNROLL
-    for (int k = 0; k < CHMC_TREE_MAXCHK; ++k) {
-      if (k < nchk) {
+    for (int kk = 0; kk < CHMC_TREE_MAXCHK; ++kk) {
+      const int k = nchk - 1 - kk;
+      if (k >= 0) {
         const double* cp = ck_p + (size_t)(lo + k) * BQ;
         const double2_ a = ldv2(cp + i, wide, two), cs = ldv2(ck_sum + (size_t)(lo + k) * BQ + i, wide, two);
-        double2_ va = a;
-        if (inu) {
-          va.x = metric_inv_u(sy, cp + cq, col);
-          if (col + 1 < sy.U) va.y = metric_inv_u(sy, cp + cq, col + 1);
-        }
+        const double2_ va = vel(cp, cq, col, a);
         const double sx = S.x - cs.x + a.x, sy_ = two ? S.y - cs.y + a.y : 0.0;
-        acc[2 * k] += va.x * sx + (two ? va.y * sy_ : 0.0);
-        acc[2 * k + 1] += vp.x * sx + (two ? vp.y * sy_ : 0.0);
+        acc[6 * k] += va.x * sx + (two ? va.y * sy_ : 0.0);
+        acc[6 * k + 1] += vp.x * sx + (two ? vp.y * sy_ : 0.0);
+        if (ck_end && kk > 0) {
+          const double* ce = ck_end + (size_t)(lo + k) * BQ;
+          const double* cr = ck_p + (size_t)(lo + k + 1) * BQ;
+          const double2_ pm = ldv2(ce + i, wide, two);
+          const double2_ vm = vel(ce, cq, col, pm), vr = vel(cr, cq, col, a_r);
+          const double r1x = cs_r.x - cs.x + a.x, r1y = two ? cs_r.y - cs.y + a.y : 0.0;
+          const double r2x = S.x - cs_r.x + a_r.x + pm.x, r2y = two ? S.y - cs_r.y + a_r.y + pm.y : 0.0;
+          acc[6 * k + 2] += va.x * r1x + (two ? va.y * r1y : 0.0);
+          acc[6 * k + 3] += vr.x * r1x + (two ? vr.y * r1y : 0.0);
+          acc[6 * k + 4] += vm.x * r2x + (two ? vm.y * r2y : 0.0);
+          acc[6 * k + 5] += vp.x * r2x + (two ? vp.y * r2y : 0.0);
+        }
+        a_r = a, cs_r = cs;
       }
+    }
+    // (the u-part of ck_end[lo] is read by every work item of the chain's first columns through the block metric: it is
+    // recorded by the second stage, KTreeLeafFinish, after this pass)
+    if (ck_end && nchk > 0) {
+      double* ce = ck_end + (size_t)lo * BQ + i;
+      if (col >= sy.U) stv2(ce, p, wide, two);
+      else if (two && col + 1 >= sy.U) ce[1] = p.y;
     }
   }
 };
 // second stage: the workgroup partials of a chain are added in a fixed order (reproducible sums);
 // out [B][2 nchk] = the two criterion values per checkpoint
 struct KTreeLeafFinish {
+  Sys sy;
+  Slots sl;
   const int* run;
   const double* partial;  // [B][nwg][nacc]
   int nwg, nacc;
   double* out;            // [B][nacc]
+  double* ck_end;         // u-part of ck_end[lo] <- momentum (see KTreeLeaf), or null
+  int lo;
   CHMC_HD void operator()(int c) const {
     double* o = out + (size_t)c * nacc;
     for (int a = 0; a < nacc; ++a) {
@@ -1998,6 +2034,11 @@ struct KTreeLeafFinish {
       if (run[c])
         for (int g = 0; g < nwg; ++g) t += partial[((size_t)c * nwg + g) * nacc + a];
       o[a] = t;
+    }
+    if (ck_end && run[c]) {
+      const double* p = pick(sl.p, sl.cur[c]) + (size_t)c * sy.Q;
+      double* ce = ck_end + ((size_t)lo * sy.B + c) * sy.Q;
+      for (int a = 0; a < sy.U; ++a) ce[a] = p[a];
     }
   }
 };

@@ -6,7 +6,10 @@ step: at tree depth d every live chain picks its own direction, resumes from its
 steps; multinomial sampling of the proposal (uniform within a sub-tree, biased progressive between the old tree and a
 new sub-tree), the no-U-turn criterion `dh_dmom(edge) . sum_mom < 0` on every sub-tree span (checked iteratively with
 O(depth) momentum checkpoints per chain instead of recursion), termination on integrator errors and on divergence
-(`delta_h > max_delta_h`) follow the reference's transition; Mici's additional "extra sub-tree checks" are not made.
+(`delta_h > max_delta_h`) follow the reference's transition, and so do Mici's additional sub-tree checks
+(`do_extra_subtree_checks`, on by default there): for every sub-tree span of four or more leaves the criterion is also
+applied from the span's first leaf to the first leaf of its right half (left half's momenta plus that leaf's) and from
+the last leaf of its left half to the span's last leaf (right half's momenta plus that leaf's).
 Tree vectors (edges, proposal, momentum sums, checkpoints) live in torch tensors on the context's device -- plumbing
 around `chmc_leapfrog_step`, which does all the work -- and the library re-evaluates a chain's state caches when its
 tree switches edges (`chmc_restore_device`), one batched evaluation per doubling at most.
@@ -47,7 +50,7 @@ class DynamicTransition:
     selected states set on the context (momentum to be refreshed by the caller)."""
 
     def __init__(self, ctx, step_size, seed, max_tree_depth=10, max_delta_h=1000.0, solver=None, chain_offset=0,
-                 total_chains=None, device=None):
+                 total_chains=None, device=None, do_extra_subtree_checks=True):
         import torch
         self.torch = torch
         self.ctx, self.step_size, self.seed = ctx, float(step_size), seed
@@ -67,6 +70,8 @@ class DynamicTransition:
         self.sum_mom, self.sub_sum = z(B, Q), z(B, Q)
         self.ck_p = z(self.max_tree_depth, B, Q)                # momentum at the first leaf of a pending span
         self.ck_sum = z(self.max_tree_depth, B, Q)              # running sub-tree momentum sum at that leaf
+        # momentum at the last leaf of the left half of a pending span (additional sub-tree checks)
+        self.ck_end = z(self.max_tree_depth, B, Q) if do_extra_subtree_checks else None
 
     # ---- helpers
     def _sync(self):
@@ -151,9 +156,10 @@ class DynamicTransition:
                 lo, hi = _ckpt_range(k)
                 even = k % 2 == 0
                 crit = ctx.tree_leaf(run, take, self.sub_prop_q.data_ptr(), self.sub_sum.data_ptr(), self.ck_p.data_ptr(),
-                                     self.ck_sum.data_ptr(), hi if even else -1, lo, 0 if even else hi - lo + 1)
+                                     self.ck_sum.data_ptr(), hi if even else -1, lo, 0 if even else hi - lo + 1,
+                                     ck_end_ptr=None if self.ck_end is None else self.ck_end.data_ptr())
                 if not even:
-                    turn = run & (crit < 0).any(1)
+                    turn = run & (crit < 0).any((1, 2))
                     alive &= ~turn
                     run &= ~turn
             done = run  # chains whose sub-tree completed without terminating

@@ -213,36 +213,47 @@ def check_tree_leaf(ctx, case, device, with_metric):
     t = lambda a: torch.from_numpy(np.array(a, copy=True)).to(device)  # noqa: E731  (a copy: on the CPU the tensor would alias `a`)
     sub_prop = rng.standard_normal((B, Q))
     sub_sum = rng.standard_normal((B, Q))
-    ck_p, ck_sum = rng.standard_normal((D, B, Q)), rng.standard_normal((D, B, Q))
+    ck_p, ck_sum, ck_end = (rng.standard_normal((D, B, Q)) for _ in range(3))
     run = (np.arange(B) % 3 != 1).astype(np.int32)
     take = (np.arange(B) % 2 == 0).astype(np.int32) & run
     W = np.eye(Q)
     if with_metric:
         W[:4, :4] = np.linalg.inv(M0)
+    dot = lambda a, rho: ((a @ W.T) * rho).sum(1) * run  # noqa: E731  dh_dmom(a) . rho
 
-    def expect(store, lo, n):
+    def expect(store, lo, n, extra):
         S = sub_sum + p0 * run[:, None]
         prop = np.where((take == 1)[:, None], q0, sub_prop)
-        cp, cs = ck_p.copy(), ck_sum.copy()
+        cp, cs, ce = ck_p.copy(), ck_sum.copy(), ck_end.copy()
         if store >= 0:
             cp[store] = np.where((run == 1)[:, None], p0, cp[store])
             cs[store] = np.where((run == 1)[:, None], S, cs[store])
-        crit = np.zeros((B, 2 * n))
+        crit = np.zeros((B, n, 6))
         for k in range(n):
-            span = S - ck_sum[lo + k] + ck_p[lo + k]
-            crit[:, 2 * k] = ((ck_p[lo + k] @ W.T) * span).sum(1) * run
-            crit[:, 2 * k + 1] = ((p0 @ W.T) * span).sum(1) * run
-        return S, prop, cp, cs, crit
+            a, csa = ck_p[lo + k], ck_sum[lo + k]
+            span = S - csa + a
+            crit[:, k, 0], crit[:, k, 1] = dot(a, span), dot(p0, span)
+            if extra and k < n - 1:  # the span of slot lo + k + 1 is the right half
+                ar, csr, pm = ck_p[lo + k + 1], ck_sum[lo + k + 1], ck_end[lo + k]
+                rho1 = csr - csa + a          # momenta of the left half + first momentum of the right half
+                rho2 = S - csr + ar + pm      # momenta of the right half + last momentum of the left half
+                crit[:, k, 2], crit[:, k, 3] = dot(a, rho1), dot(ar, rho1)
+                crit[:, k, 4], crit[:, k, 5] = dot(pm, rho2), dot(p0, rho2)
+        if extra and n > 0:
+            ce[lo] = np.where((run == 1)[:, None], p0, ce[lo])
+        return S, prop, cp, cs, ce, crit
 
-    for store, lo, n in ((2, 0, 0), (-1, 1, 3), (-1, 0, 1)):
-        d_prop, d_sum, d_cp, d_cs = t(sub_prop), t(sub_sum), t(ck_p), t(ck_sum)
+    for store, lo, n, extra in ((2, 0, 0, True), (-1, 1, 3, True), (-1, 0, 1, True), (-1, 0, 4, True), (-1, 1, 3, False)):
+        d_prop, d_sum, d_cp, d_cs, d_ce = t(sub_prop), t(sub_sum), t(ck_p), t(ck_sum), t(ck_end)
         if device != "cpu":
             torch.cuda.synchronize()
-        crit = ctx.tree_leaf(run, take, d_prop.data_ptr(), d_sum.data_ptr(), d_cp.data_ptr(), d_cs.data_ptr(), store, lo, n)
-        S, prop, cp, cs, ecrit = expect(store, lo, n)
+        crit = ctx.tree_leaf(run, take, d_prop.data_ptr(), d_sum.data_ptr(), d_cp.data_ptr(), d_cs.data_ptr(), store, lo, n,
+                             ck_end_ptr=d_ce.data_ptr() if extra else None)
+        S, prop, cp, cs, ce, ecrit = expect(store, lo, n, extra)
         np.testing.assert_allclose(d_sum.cpu().numpy(), S, rtol=0, atol=1e-14)
         np.testing.assert_array_equal(d_prop.cpu().numpy(), prop)
         np.testing.assert_array_equal(d_cp.cpu().numpy(), cp)
+        np.testing.assert_array_equal(d_ce.cpu().numpy(), ce)
         np.testing.assert_allclose(d_cs.cpu().numpy(), cs, rtol=0, atol=1e-14)
         np.testing.assert_allclose(crit, ecrit, rtol=1e-11, atol=1e-9)
     ctx.set_metric(None)

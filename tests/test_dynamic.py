@@ -5,7 +5,7 @@ import numpy as np
 from test_emu_logic import emu_lib  # noqa: F401
 
 
-def _reference_transition(ctx1, q, p, xo, part, draw, eps, max_depth, max_delta_h, solver, W=None):
+def _reference_transition(ctx1, q, p, xo, part, draw, eps, max_depth, max_delta_h, solver, W=None, extra=True):
     def vel(pp):  # dh_dmom = metric.inv @ mom (sde/mici_extensions.py:1204-1208)
         if W is None:
             return pp
@@ -48,6 +48,14 @@ def _reference_transition(ctx1, q, p, xo, part, draw, eps, max_depth, max_delta_
                 span = sum(pp for _, pp in leaves[a:k + 1])
                 if vel(leaves[a][1]) @ span < 0 or vel(leaves[k][1]) @ span < 0:
                     ok = False
+                if extra and j >= 2:  # Mici's additional checks across the two halves of the span
+                    m = a + (1 << (j - 1)) - 1
+                    rho1 = sum(pp for _, pp in leaves[a:m + 1]) + leaves[m + 1][1]
+                    rho2 = sum(pp for _, pp in leaves[m + 1:k + 1]) + leaves[m][1]
+                    if vel(leaves[a][1]) @ rho1 < 0 or vel(leaves[m + 1][1]) @ rho1 < 0:
+                        ok = False
+                    if vel(leaves[m][1]) @ rho2 < 0 or vel(leaves[k][1]) @ rho2 < 0:
+                        ok = False
                 j += 1
             if not ok:
                 break
@@ -69,8 +77,8 @@ def _reference_transition(ctx1, q, p, xo, part, draw, eps, max_depth, max_delta_
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("with_metric", [False, True])
-def test_batched_tree_equals_single_chain_restatement(emu_lib, with_metric):  # noqa: F811
+@pytest.mark.parametrize("with_metric,extra", [(False, True), (True, True), (False, False)])
+def test_batched_tree_equals_single_chain_restatement(emu_lib, with_metric, extra):  # noqa: F811
     from manifold_mcmc_for_diffusions_amd import example_models as em
     from manifold_mcmc_for_diffusions_amd.init import fhn_initial_states
     from manifold_mcmc_for_diffusions_amd.context import ChmcContext
@@ -89,7 +97,7 @@ def test_batched_tree_equals_single_chain_restatement(emu_lib, with_metric):  # 
         M0 = a @ a.T / 4 + 0.5 * np.eye(4)
         ctx.set_metric(M0), ctx1.set_metric(M0)
         W = np.linalg.inv(M0)
-    tr = DynamicTransition(ctx, eps, seed=11, max_tree_depth=depth)
+    tr = DynamicTransition(ctx, eps, seed=11, max_tree_depth=depth, do_extra_subtree_checks=extra)
     n_total = 0
     for it in range(5):
         ctx.sample_momentum(11, it + 1)
@@ -99,7 +107,8 @@ def test_batched_tree_equals_single_chain_restatement(emu_lib, with_metric):  # 
         un = TreeUniforms(11, it, B, 0, B)
         for c in range(B):
             prop, n = _reference_transition(ctx1, q0[c], p0[c], xo0[c], part,
-                                            lambda kind, d, k, c=c: un.get(kind, d, k)[c], eps, depth, 1000.0, tr.solver, W)
+                                            lambda kind, d, k, c=c: un.get(kind, d, k)[c], eps, depth, 1000.0, tr.solver, W,
+                                            extra)
             assert n == st["n_step"][c], (it, c, n, st["n_step"][c])
             np.testing.assert_allclose(q1[c], prop, rtol=0, atol=1e-9)
             n_total += n
