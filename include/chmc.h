@@ -112,6 +112,33 @@ int chmc_set_metric(chmc_ctx* ctx, const double* M_0);
 int chmc_tree_leaf(chmc_ctx* ctx, const int* run, const int* take, void* sub_prop_q_dev, void* sub_sum_dev,
                    void* ck_p_dev, void* ck_sum_dev, void* ck_end_dev, int store_slot, int check_lo, int n_check,
                    double* out);
+/* The per-chain decisions of the same transition taken on the device, so that a leaf of the batched trees costs one
+ * call and one 4-byte read-back instead of three host round trips (mici _build_tree's base case and its termination
+ * logic, scripts/utils.py:292-301).  The library keeps per chain: h0 (Hamiltonian at the tree's root), alive (the tree
+ * can still grow), run (the chain takes part in the current sub-tree), the sub-tree's multinomial log weight, the
+ * number of leaves, the sum of the leaves' acceptance probabilities min(1, exp(h0 - h)), and the integrator-error /
+ * divergence flags.
+ *   chmc_tree_begin    h0 = Hamiltonian of the current states (returned in h0[B] if not NULL), alive = isfinite(h0),
+ *                      counters and flags cleared;
+ *   chmc_tree_set_alive overrides alive[B] (the caller ends a chain's tree on its whole-tree criterion);
+ *   chmc_tree_subtree  run = alive, sub-tree weight = 0 (log weight -inf);
+ *   chmc_tree_step     for the chains with run != 0: one chmc_leapfrog_step (same arguments), then
+ *                      integrator error (status != 0) -> failed, alive = run = 0; else delta_h = h - h0 > max_delta_h or
+ *                      NaN -> diverged, alive = run = 0; else the leaf joins the sub-tree: n_step += 1, sum_acc +=
+ *                      min(1, exp(h0 - h)), weight += exp(-h), take = u_leaf[c] < exp(-h) / weight; then the
+ *                      bookkeeping of chmc_tree_leaf with these run / take (same buffers and slot arguments), and a
+ *                      negative criterion value on any checked span sets alive = run = 0 (no-U-turn termination).
+ *                      *n_running = number of chains with run != 0 afterwards;
+ *   chmc_tree_get      per-chain state to the host (any pointer may be NULL). */
+int chmc_tree_begin(chmc_ctx* ctx, double* h0);
+int chmc_tree_set_alive(chmc_ctx* ctx, const int* alive);
+int chmc_tree_subtree(chmc_ctx* ctx);
+int chmc_tree_step(chmc_ctx* ctx, const double* dt, int n_inner_step, int newton, double constraint_tol, double position_tol,
+                   double divergence_tol, int max_iters, double reverse_check_tol, const double* u_leaf, double max_delta_h,
+                   void* sub_prop_q_dev, void* sub_sum_dev, void* ck_p_dev, void* ck_sum_dev, void* ck_end_dev,
+                   int store_slot, int check_lo, int n_check, int* n_running);
+int chmc_tree_get(chmc_ctx* ctx, int* alive, int* run, int* n_step, int* failed, int* diverged, double* sub_logw,
+                  double* sum_acc);
 int chmc_set_momentum(chmc_ctx* ctx, const double* p);
 int chmc_get_state_device(chmc_ctx* ctx, void* q_dev, void* p_dev);  /* device-to-device copies */
 int chmc_set_momentum_device(chmc_ctx* ctx, const void* p_dev);

@@ -40,6 +40,13 @@ SYMBOLS = [
     ("chmc_set_metric", C.c_int, [C.c_void_p, dp]),
     ("chmc_tree_leaf", C.c_int, [C.c_void_p, ip, ip, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_int, C.c_int, dp]),
+    ("chmc_tree_begin", C.c_int, [C.c_void_p, dp]),
+    ("chmc_tree_set_alive", C.c_int, [C.c_void_p, ip]),
+    ("chmc_tree_subtree", C.c_int, [C.c_void_p]),
+    ("chmc_tree_step", C.c_int, [C.c_void_p, dp, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double,
+                                 dp, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                 C.c_int, C.c_int, ip]),
+    ("chmc_tree_get", C.c_int, [C.c_void_p, ip, ip, ip, ip, ip, dp, dp]),
     ("chmc_set_momentum", C.c_int, [C.c_void_p, dp]),
     ("chmc_get_state_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("chmc_set_momentum_device", C.c_int, [C.c_void_p, C.c_void_p]),

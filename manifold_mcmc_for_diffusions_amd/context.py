@@ -123,6 +123,43 @@ class ChmcContext:
               "chmc_tree_leaf")
         return out
 
+    # ---- per-chain tree decisions on the device (chmc_tree_begin / _subtree / _step / _get, include/chmc.h)
+    def tree_begin(self):
+        h0 = np.empty(self.B)
+        check(self.L.chmc_tree_begin(self.h, ptr(h0)), "chmc_tree_begin")
+        return h0
+
+    def tree_set_alive(self, alive):
+        a = np.ascontiguousarray(alive, dtype=np.int32)
+        check(self.L.chmc_tree_set_alive(self.h, iptr(a)), "chmc_tree_set_alive")
+
+    def tree_subtree(self):
+        check(self.L.chmc_tree_subtree(self.h), "chmc_tree_subtree")
+
+    def tree_step(self, dt, u_leaf, max_delta_h, sub_prop_q_ptr, sub_sum_ptr, ck_p_ptr, ck_sum_ptr, ck_end_ptr, store_slot,
+                  check_lo, n_check, n_inner_step=1, newton=True, constraint_tol=1e-9, position_tol=1e-8,
+                  divergence_tol=1e10, max_iters=50, reverse_check_tol=2e-8):
+        """One leaf for every chain still running in its sub-tree: integrator step, termination tests, multinomial
+        weight / proposal update, momentum sums, checkpoints and no-U-turn checks, all on the device.  Returns the
+        number of chains still running."""
+        dt = as_c(np.broadcast_to(np.asarray(dt, dtype=np.float64), (self.B,)))
+        u = as_c(np.asarray(u_leaf, dtype=np.float64))
+        n = C.c_int(0)
+        check(self.L.chmc_tree_step(self.h, ptr(dt), int(n_inner_step), int(newton), constraint_tol, position_tol,
+                                    divergence_tol, int(max_iters), reverse_check_tol, ptr(u), float(max_delta_h),
+                                    C.c_void_p(sub_prop_q_ptr), C.c_void_p(sub_sum_ptr), C.c_void_p(ck_p_ptr),
+                                    C.c_void_p(ck_sum_ptr), C.c_void_p(ck_end_ptr or 0), int(store_slot), int(check_lo),
+                                    int(n_check), C.byref(n)), "chmc_tree_step")
+        return n.value
+
+    def tree_get(self):
+        B = self.B
+        o = {k: np.zeros(B, dtype=np.int32) for k in ("alive", "run", "n_step", "failed", "diverged")}
+        o["sub_logw"], o["sum_acc"] = np.zeros(B), np.zeros(B)
+        check(self.L.chmc_tree_get(self.h, iptr(o["alive"]), iptr(o["run"]), iptr(o["n_step"]), iptr(o["failed"]),
+                                   iptr(o["diverged"]), ptr(o["sub_logw"]), ptr(o["sum_acc"])), "chmc_tree_get")
+        return o
+
     def set_momentum(self, p):
         p = self._bq(p, "p")
         check(self.L.chmc_set_momentum(self.h, ptr(p)), "chmc_set_momentum")

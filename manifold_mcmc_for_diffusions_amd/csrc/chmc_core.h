@@ -2042,6 +2042,90 @@ struct KTreeLeafFinish {
     }
   }
 };
+// ---- per-chain decisions of the batched dynamic transition on the device (chmc_tree_begin / _subtree / _step in
+// include/chmc.h; the logic of mici's MultinomialDynamicIntegrationTransition._build_tree base case, per chain)
+struct TreeState {
+  double *h0, *sub_logw, *sum_acc, *u;  // [B] Hamiltonian at the tree's root, log weight of the current sub-tree, sum of
+                                        // the leaves' acceptance probabilities, this leaf's uniform draw
+  int *alive, *run, *take, *n_step, *failed, *diverged;  // [B]
+  int* n_running;                                        // [1]
+};
+CHMC_HD inline double log_add_exp(double a, double b) {  // log(exp(a) + exp(b)), the formula of numpy.logaddexp
+  if (a == b) return a + 0.6931471805599453;             // (also covers -inf, -inf)
+  const double d = a - b;
+  if (d > 0.0) return a + log1p(exp(-d));
+  if (d <= 0.0) return b + log1p(exp(d));
+  return a + b;  // NaN
+}
+struct KTreeBegin {
+  TreeState t;
+  const double* ham;    // [B][3] chmc_hamiltonian of the current states
+  CHMC_HD void operator()(int c) const {
+    const double h = ham[(size_t)c * 3];
+    t.h0[c] = h;
+    t.alive[c] = (h - h == 0.0) ? 1 : 0;  // finite
+    t.run[c] = 0, t.take[c] = 0, t.n_step[c] = 0, t.failed[c] = 0, t.diverged[c] = 0;
+    t.sum_acc[c] = 0.0;
+    t.sub_logw[c] = -__builtin_huge_val();
+  }
+};
+struct KTreeSubBegin {  // a new sub-tree: every live chain runs, empty multinomial weight
+  TreeState t;
+  CHMC_HD void operator()(int c) const {
+    t.run[c] = t.alive[c];
+    t.sub_logw[c] = -__builtin_huge_val();
+  }
+};
+// after the integrator step of a leaf: integrator errors and divergence (delta_h > max_delta_h, NaN counts as
+// divergent) end the chain's tree; otherwise the leaf joins the sub-tree (step count, acceptance statistic, multinomial
+// weight) and becomes its proposal with probability exp(-h) / (sub-tree weight including this leaf)
+struct KTreeDecide {
+  TreeState t;
+  const int* status;  // of the step just taken
+  const double* ham;  // [B][3] at the new states
+  double max_delta_h;
+  CHMC_HD void operator()(int c) const {
+    t.take[c] = 0;
+    if (!t.run[c]) return;
+    const double h = ham[(size_t)c * 3], h0 = t.h0[c];
+    const bool bad = status[c] != 0;
+    const bool div = !bad && !((h - h0) <= max_delta_h);
+    if (bad) t.failed[c] = 1;
+    if (div) t.diverged[c] = 1;
+    if (bad || div) {
+      t.alive[c] = 0, t.run[c] = 0;
+      return;
+    }
+    t.n_step[c] += 1;
+    const double d = h0 - h;
+    t.sum_acc[c] += fmin(1.0, exp(d < 0.0 ? d : 0.0));
+    const double nw = log_add_exp(t.sub_logw[c], -h);
+    t.take[c] = t.u[c] < exp(-h - nw) ? 1 : 0;
+    t.sub_logw[c] = nw;
+  }
+};
+// after KTreeLeaf / KTreeLeafFinish of an odd leaf: a negative criterion value on any checked span ends the chain's tree
+struct KTreeTurn {
+  TreeState t;
+  const double* out;  // [B][nacc]
+  int nacc;
+  CHMC_HD void operator()(int c) const {
+    if (!t.run[c]) return;
+    bool turn = false;
+    for (int a = 0; a < nacc; ++a) turn = turn || out[(size_t)c * nacc + a] < 0.0;
+    if (turn) t.alive[c] = 0, t.run[c] = 0;
+  }
+};
+struct KTreeCount {
+  TreeState t;
+  int B;
+  CHMC_HD void operator()(int tid) const {
+    if (tid != 0) return;
+    int n = 0;
+    for (int c = 0; c < B; ++c) n += t.run[c] != 0;
+    t.n_running[0] = n;
+  }
+};
 // q.q and p.p of the current state for the Hamiltonian (:1186-1202), row-sum launch: acc[0] += q.q, acc[1] += p.p
 struct KNormRow {
   Sys sy;

@@ -11,8 +11,10 @@ O(depth) momentum checkpoints per chain instead of recursion), termination on in
 applied from the span's first leaf to the first leaf of its right half (left half's momenta plus that leaf's) and from
 the last leaf of its left half to the span's last leaf (right half's momenta plus that leaf's).
 Tree vectors (edges, proposal, momentum sums, checkpoints) live in torch tensors on the context's device -- plumbing
-around `chmc_leapfrog_step`, which does all the work -- and the library re-evaluates a chain's state caches when its
-tree switches edges (`chmc_restore_device`), one batched evaluation per doubling at most.
+around the integrator step, which does all the work -- and the library re-evaluates a chain's state caches when its
+tree switches edges (`chmc_restore_device`), one batched evaluation per doubling at most.  The per-chain decisions of
+a leaf are taken on the device (`chmc_tree_step`: one library call and one 4-byte read-back per leaf); the host keeps
+the per-doubling logic (direction, biased progressive sampling, whole-tree criterion).
 
 All random choices come from `TreeUniforms`, keyed by (seed, transition, purpose, depth, leaf) and the global chain
 index, so results do not depend on how chains are sharded or on the order in which an implementation asks for them.
@@ -101,7 +103,10 @@ class DynamicTransition:
         B = ctx.B
         un = TreeUniforms(self.seed, it, self.total, self.off, B)
         self._fetch()
-        h0 = ctx.hamiltonian()[:, 0]
+        # per-chain tree state lives in the library (chmc_tree_*): the decisions of a leaf -- integrator error,
+        # divergence, multinomial weight and proposal, no-U-turn termination of sub-tree spans -- are taken on the
+        # device; the host sees the number of chains still running after a leaf and the per-chain state after a sub-tree
+        h0 = ctx.tree_begin()
         for t in (self.neg_q, self.pos_q, self.prop_q):
             t.copy_(self.q)
         for t in (self.neg_p, self.pos_p, self.sum_mom):
@@ -111,9 +116,9 @@ class DynamicTransition:
         at_neg = np.ones(B, dtype=bool)
         alive = np.isfinite(h0)
         moved = np.zeros(B, dtype=bool)
-        sum_acc, n_step = np.zeros(B), np.zeros(B, dtype=np.int64)
         depth_reached = np.zeros(B, dtype=np.int64)
-        diverged, failed = np.zeros(B, dtype=bool), np.zeros(B, dtype=bool)
+        ck_end = None if self.ck_end is None else self.ck_end.data_ptr()
+        st = None
         for d in range(self.max_tree_depth):
             if not alive.any():
                 break
@@ -129,50 +134,33 @@ class DynamicTransition:
             at_neg = np.where(alive, ~fwd, at_neg)
             dt = np.where(fwd, self.step_size, -self.step_size)
             # ---- sub-tree of 2^d leaves
-            run = alive.copy()
-            sub_logw = np.full(B, -np.inf)
             self.sub_sum.zero_()
             self._sync()  # the library works on its own stream
+            ctx.tree_subtree()
             for k in range(1 << d):
-                if not run.any():
-                    break
-                r = ctx.leapfrog_step(dt, active=run.astype(np.int32), **self.solver)
-                bad = run & (r["status"] != 0)
-                failed |= bad
-                h = ctx.hamiltonian()[:, 0]
-                div = run & ~bad & ~((h - h0) <= self.max_delta_h)   # NaN counts as divergent
-                diverged |= div
-                stop = bad | div
-                alive &= ~stop
-                run &= ~stop
-                n_step += run
-                sum_acc += np.where(run, np.minimum(1.0, np.exp(np.minimum(0.0, h0 - h))), 0.0)
-                leaf_logw = np.where(run, -h, -np.inf)
-                new_logw = np.logaddexp(sub_logw, leaf_logw)
-                take = run & (un.get(un.LEAF, d, k) < np.exp(np.where(run, leaf_logw - np.where(run, new_logw, 0.0), -np.inf)))
-                sub_logw = np.where(run, new_logw, sub_logw)
-                # one fused pass over the new state (chmc_tree_leaf): momentum sum, multinomial proposal, checkpoint of an
-                # even leaf, and for an odd leaf the iterative no-U-turn checks over every sub-tree span that ends here
                 lo, hi = _ckpt_range(k)
                 even = k % 2 == 0
-                crit = ctx.tree_leaf(run, take, self.sub_prop_q.data_ptr(), self.sub_sum.data_ptr(), self.ck_p.data_ptr(),
-                                     self.ck_sum.data_ptr(), hi if even else -1, lo, 0 if even else hi - lo + 1,
-                                     ck_end_ptr=None if self.ck_end is None else self.ck_end.data_ptr())
-                if not even:
-                    turn = run & (crit < 0).any((1, 2))
-                    alive &= ~turn
-                    run &= ~turn
-            done = run  # chains whose sub-tree completed without terminating
+                # one call per leaf: integrator step + (chmc_tree_step) momentum sum, multinomial proposal, checkpoint of
+                # an even leaf, and for an odd leaf the no-U-turn checks over every sub-tree span that ends here
+                n_run = ctx.tree_step(dt, un.get(un.LEAF, d, k), self.max_delta_h, self.sub_prop_q.data_ptr(),
+                                      self.sub_sum.data_ptr(), self.ck_p.data_ptr(), self.ck_sum.data_ptr(), ck_end,
+                                      hi if even else -1, lo, 0 if even else hi - lo + 1, **self.solver)
+                if n_run == 0:
+                    break
+            st = ctx.tree_get()
+            alive = st["alive"] != 0
+            done = st["run"] != 0  # chains whose sub-tree completed without terminating
+            sub_logw = st["sub_logw"]
             if not done.any():
                 continue
             self._fetch()  # state after the sub-tree's last leaf: the tree's new edge
             depth_reached = np.where(done, d + 1, depth_reached)
             # biased progressive sampling between the old tree and the new sub-tree
-            acc = done & (un.get(un.ACCEPT, d) < np.exp(np.minimum(0.0, sub_logw - logw)))
+            acc = done & (un.get(un.ACCEPT, d) < np.exp(np.minimum(0.0, np.where(done, sub_logw - logw, -np.inf))))
             moved |= acc
             am, dm = self._mask(acc), self._mask(done)
             self.prop_q.copy_(torch.where(am[:, None], self.sub_prop_q, self.prop_q))
-            logw = np.where(done, np.logaddexp(logw, sub_logw), logw)
+            logw = np.where(done, np.logaddexp(logw, np.where(done, sub_logw, -np.inf)), logw)
             self.sum_mom.add_(torch.where(dm[:, None], self.sub_sum, torch.zeros_like(self.sub_sum)))
             fm = self._mask(done & fwd)[:, None]
             bm = self._mask(done & ~fwd)[:, None]
@@ -182,12 +170,17 @@ class DynamicTransition:
             self.neg_p.copy_(torch.where(bm, self.p, self.neg_p))
             # no-U-turn criterion on the whole tree (riemannian_no_u_turn_criterion: dh_dmom(edge) . sum of momenta)
             turn = ((self._dot(self.neg_p, self.sum_mom) < 0) | (self._dot(self.pos_p, self.sum_mom) < 0)).cpu().numpy()
-            alive &= ~(done & turn)
+            if (done & turn).any():
+                alive = alive & ~(done & turn)
+                ctx.tree_set_alive(alive.astype(np.int32))
+        if st is None:
+            st = ctx.tree_get()
         # leave the selected positions on the context (every chain: the context may sit on a tree edge)
         self._sync()
         ctx.restore_device(self.prop_q.data_ptr(), self.p.data_ptr(), np.ones(B, dtype=np.int32), False)
-        return dict(accept_stat=sum_acc / np.maximum(n_step, 1), n_step=n_step, depth=depth_reached, moved=moved,
-                    diverged=diverged, integrator_error=failed)
+        n_step = st["n_step"].astype(np.int64)
+        return dict(accept_stat=st["sum_acc"] / np.maximum(n_step, 1), n_step=n_step, depth=depth_reached, moved=moved,
+                    diverged=st["diverged"] != 0, integrator_error=st["failed"] != 0)
 
 
 def sample_dynamic_chmc(ctx, n_iter, step_size, seed, n_adapt=0, chain_offset=0, total_chains=None, n_head=6,

@@ -40,7 +40,8 @@ def timed(obj, name):
     setattr(obj, name, g)
 
 
-for nm in ("leapfrog_step", "hamiltonian", "tree_leaf", "get_state_device", "restore_device", "sample_momentum", "switch_partition"):
+for nm in ("tree_begin", "tree_subtree", "tree_step", "tree_get", "tree_set_alive", "get_state_device", "restore_device", "sample_momentum",
+           "switch_partition"):
     timed(ctx, nm)
 tr = DynamicTransition(ctx, 0.09, seed=3, max_tree_depth=5)
 torch.cuda.synchronize()
