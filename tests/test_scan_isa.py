@@ -67,3 +67,15 @@ def test_forward_scan_kernels_keep_in_flight_registers_untouched():
     r = subprocess.run([sys.executable, TOOL], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("ok   ") >= 10
+    assert r.stdout.count("untracked stores") >= 10  # the store audit of the sweeps that use st_async ran
+
+
+def test_store_audit_flags_a_store_without_its_nop_and_flat_accesses():
+    t = _tool()
+    good = ["k:", "\t;;#ASMSTART", "\tglobal_store_dwordx2 v[0:1], v[2:3], off", "\ts_nop 1", "\t;;#ASMEND", "\ts_endpgm"]
+    assert t.audit_stores("k", good) == ([], 1, 0)
+    bad = good[:3] + ["\t;;#ASMEND", "\tscratch_store_dword off, v2, off", "\ts_endpgm"]
+    probs, n_st, n_scr = t.audit_stores("k", bad)
+    assert n_st == 1 and n_scr == 1 and any("without its s_nop" in p for p in probs)
+    probs, _, _ = t.audit_stores("k", good[:-1] + ["\tflat_load_dword v4, v[0:1]", "\ts_endpgm"])
+    assert any("flat_" in p for p in probs)
