@@ -49,6 +49,7 @@ struct Sys {
   int varsig;  // observation noise sigma = generate_sigma(u) = exp(u[Z]) (fhn.py:46-47, sir.py:92-93): U = Z + 1
   int U, X, V, Z, V0;
   int Q, NV, K, C, Kmax, RM, TRJ, NCOL;  // NCOL = NV + (noisy ? T : 0)
+  int NOBS;  // most observations in one block, over both partitions (interval frames LF)
   double dl, sigma;
   const double* y;
   const double* xobs;  // [B][T][X]
@@ -91,10 +92,18 @@ struct Slots {
   double* logdet[2];
   double* grad[2];
   double* pg[2];  // [B][Q] P(q) dh1_dpos(q): the projected gradient of the slot's state (see chmc_leapfrog_step)
+  // Compact form of the stored dc/dv rows (blocks of at most 8 rows, wave kernels): inside observation interval m of a
+  // block every row is the interval's frame applied to ONE row-independent matrix per step,
+  //     dc_i/dv_s = LF[m][i] . PB[s],   PB[s] = Pf E_s B_s  (X x V),   LF[m][i] = the adjoint row i at the interval's end,
+  // so the passes of a Newton iteration over the previous point's Jacobian (J^T lambda in KUpdatePB, the Gram
+  // contraction in k_newton_lean) read X V doubles per step instead of up to RM V.  Null when not in use.
+  double* PB[2];  // [B][T S][X V]
+  double* LF[2];  // [B][Kmax][NOBS][RM][X]
   int* cur;
 };
 
 struct Work {
+  double* muF;      // [B][Kmax][NOBS][X]  sum_i lambda_i LF[m][i]: the multipliers applied to the interval frames
   double* trajw;    // [B][TRJ]      trajectory of the Newton iterate
   double* cpad;     // [B][Kmax][RM] constraint values, block-padded
   double* cpad2;    // [B][Kmax][RM] second right-hand side of a two-vector projection
@@ -1499,6 +1508,119 @@ struct KUpdate {
     } else {
       tgt[qi] = old[0];
       if (TGT == 3) tgt2[qi] = old2[0];
+    }
+    return r;
+  }
+};
+
+// J^T lambda of a Newton / quasi-Newton iteration from the compact rows (Slots::PB, Slots::LF):
+//   KMuF      muF[c][b][m] = sum_i lambda_i LF[m][i]                       (one work item per entry, tiny)
+//   KUpdatePB q_v[s] -= muF[m(s)] . PB[s] for every step s, max |delta| per chain; the v_0 and observation-noise columns
+//             as in KUpdate (from the stored rows / sigma lambda).  Column-max launch over T S + V0 + (noisy ? T : 0) items.
+template <int RM, int X>
+struct KMuF {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which;
+  CHMC_HD void operator()(int tid) const {
+    const int a = tid % X;
+    int r = tid / X;
+    const int m = r % sy.NOBS;
+    r /= sy.NOBS;
+    const int b = r % sy.K, c = r / sy.K;
+    if (w.nw[c] != 1) return;
+    const size_t cb = (size_t)c * sy.Kmax + b;
+    double t = 0.0;
+    if (m < sy.blk[b].nobs) {
+      const double* lam = w.lampad + cb * RM;
+      const double* lf = pick(sl.LF, sl.cur[c] ^ which) + (cb * sy.NOBS + m) * RM * X;
+      const int nr = sy.blk[b].nrows;
+      for (int i = 0; i < RM; ++i)
+        if (i < nr) t += lam[i] * lf[i * X + a];
+    }
+    w.muF[(cb * sy.NOBS + m) * X + a] = t;
+  }
+};
+template <int RM, int X, int V>
+struct KUpdatePB {
+  Sys sy;
+  Slots sl;
+  Work w;
+  int which, qsel;
+  CHMC_HD bool active(int c) const { return w.nw[c] == 1; }
+  CHMC_HD unsigned long long* red(int c) const { return &w.ndq[c]; }
+  CHMC_HD unsigned long long operator()(int c, int idx) const {
+    const int s = sl.cur[c] ^ which;
+    double* tgt = (qsel ? w.qb : pick(sl.q, s ^ 1)) + (size_t)c * sy.Q + sy.U;
+    const int TS = sy.T * sy.S;
+    unsigned long long r = 0ULL;
+    if (idx < TS) {
+      const int g = idx / sy.S;  // observation interval
+      const int b = sy.obs2blk[g];
+      const int m = g - sy.blk[b].obs0;
+      const double* mu = w.muF + (((size_t)c * sy.Kmax + b) * sy.NOBS + m) * X;
+      const double* pb = pick(sl.PB, s) + ((size_t)c * TS + idx) * (X * V);
+      double* t = tgt + sy.V0 + (size_t)idx * V;
+      const bool wide = V == 2 && !((sy.Q | sy.U | sy.V0) & 1);
+      double old[V], pbv[X * V], d[V];
+      if (wide) {
+        const double2_ o = *reinterpret_cast<const double2_*>(t);
+        old[0] = o.x, old[V - 1] = o.y;
+      } else {
+        CHMC_UNROLL
+        for (int k = 0; k < V; ++k) old[k] = t[k];
+      }
+      if ((X * V) % 2 == 0) {
+        CHMC_UNROLL
+        for (int k = 0; k < X * V; k += 2) {
+          const double2_ v = ld2_stream(pb + k);
+          pbv[k] = v.x, pbv[k + 1 < X * V ? k + 1 : k] = v.y;
+        }
+      } else {
+        CHMC_UNROLL
+        for (int k = 0; k < X * V; ++k) pbv[k] = pb[k];
+      }
+      CHMC_UNROLL
+      for (int k = 0; k < V; ++k) {
+        double tt = 0.0;
+        CHMC_UNROLL
+        for (int a = 0; a < X; ++a) tt += mu[a] * pbv[a * V + k];
+        d[k] = tt;
+        const unsigned long long vb = absbits(tt);
+        r = vb > r ? vb : r;
+        old[k] -= tt;
+      }
+      if (wide) {
+        double2_ o;
+        o.x = old[0], o.y = old[V - 1];
+        *reinterpret_cast<double2_*>(t) = o;
+      } else {
+        CHMC_UNROLL
+        for (int k = 0; k < V; ++k) t[k] = old[k];
+      }
+    } else {
+      const int e = idx - TS;
+      double d;
+      int col;
+      if (e < sy.V0) {  // v_0 columns: the first block's stored rows
+        col = e;
+        const int b = sy.obs2blk[0];
+        const double* lam = w.lampad + ((size_t)c * sy.Kmax + b) * RM;
+        const double* Jv = pick(sl.Jv, s) + (size_t)c * RM * sy.NV + col;
+        const int nr = sy.blk[b].nrows;
+        d = 0.0;
+        for (int i = 0; i < RM; ++i)
+          if (i < nr) d += Jv[(size_t)i * sy.NV] * lam[i];
+      } else {  // observation-noise columns: dc/dn = sigma on the y rows (:601-608)
+        const int t = e - sy.V0;
+        col = sy.NV + t;
+        const int b = sy.obs2blk[t];
+        const int j = t - sy.blk[b].obs0;
+        d = j < sy.blk[b].ny ? sigma_at(sy, pick(sl.q, s) + (size_t)c * sy.Q) * w.lampad[((size_t)c * sy.Kmax + b) * RM + j] : 0.0;
+      }
+      r = absbits(d);
+      tgt[col] -= d;
     }
     return r;
   }

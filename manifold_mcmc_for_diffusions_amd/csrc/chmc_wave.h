@@ -195,6 +195,9 @@ __device__ __forceinline__ void dpp_rowaffine_prefix(double* I2, double* g) {
 // GRAM false (16-row blocks): no Gram accumulation -- the rows are stored (MODE 0: into the slot, MODE 1: into
 // work.JvW) and k_gram_rows forms the Gram block from the stored rows.  A 16 x 16 accumulator per lane does not fit
 // the register file: with it the sweep ran out of scratch memory, 25x slower than the 8-row instantiations.
+#ifndef CHMC_REV_ZW
+#define CHMC_REV_ZW 1
+#endif
 template <class M, int RM, int MODE, bool GRAM = true>
 __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int which, int qsel) {
   constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0;
@@ -214,9 +217,6 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   // The hot loop therefore carries 8 + 14 (Newton) or 8 + 4 (state) running sums per lane for FitzHugh-Nagumo instead
   // of 28 + 49, does not form the rows at all in a Newton iteration, and the RM-sized products are taken once per
   // interval (flush_frame), where the rows for the next interval are formed as LamF Pf as well.
-#ifndef CHMC_REV_ZW
-#define CHMC_REV_ZW 1
-#endif
   constexpr bool ZW = CHMC_REV_ZW && GRAM;
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -232,6 +232,15 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   const double* traj = (MODE == 1 ? w.trajw : pick(sl.traj, sl_)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
   const double* Jr = pick(sl.Jv, sl_) + (size_t)c * RM * NV;  // MODE 1: read; MODE 0: written through Jo
   double* Jo = (MODE == 1 ? w.JvW : pick(sl.Jv, sl_)) + (size_t)c * RM * NV;
+  double* PBo = nullptr;  // compact rows of the evaluated state (MODE 0 with frames): Slots::PB / Slots::LF
+  double* LFo = nullptr;
+  if (MODE == 0 && CHMC_REV_ZW && GRAM) {
+    double* pb0 = pick(sl.PB, sl_);
+    if (pb0) {
+      PBo = pb0 + (size_t)c * sy.T * sy.S * (X * V);
+      LFo = pick(sl.LF, sl_) + cb * sy.NOBS * RM * X;
+    }
+  }
   ChainConsts<M> cc;
   cc.init(q, sy.dl);
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
@@ -417,6 +426,16 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
       if (MODE == 0) {
         if (r.valid) {  // the rows of this step, dc_i/dv_s = LamF_i T_s, go straight to memory
           const size_t col0 = colb + (size_t)r.s * V;
+          if (PBo) {  // ... and T_s itself: the compact form of the rows (Slots::PB)
+            double* dst = PBo + (size_t)(bd.step0 + r.s) * (X * V);
+            if ((X * V) % 2 == 0) {
+#pragma unroll
+              for (int k = 0; k + 1 < X * V; k += 2) st_async2(dst + k, T[k], T[k + 1]);
+            } else {
+#pragma unroll
+              for (int k = 0; k < X * V; ++k) st_async(dst + k, T[k]);
+            }
+          }
 #pragma unroll
           for (int i = 0; i < RM; ++i) {
             double jr0[V];
@@ -571,6 +590,11 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
       if (ZW) {
 #pragma unroll
         for (int i = 0; i < RM * X; ++i) LamF[i] = Lam[i];
+        if (MODE == 0 && LFo && lane == 0) {  // the frame of interval j (Slots::LF)
+          double* dst = LFo + (size_t)j * RM * X;
+#pragma unroll
+          for (int i = 0; i < RM * X; ++i) dst[i] = Lam[i];
+        }
       }
     }
     stage1(r1, sc1);  // tile tt - 1 (identity when there is none)
@@ -680,11 +704,14 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
 #ifndef CHMC_LEAN_WAVES
 #define CHMC_LEAN_WAVES 2
 #endif
-template <class M, int RM>
+// PBJ: the previous point's rows are read in their compact form (Slots::PB / LF): X V doubles per step instead of RM V,
+// an X x X running sum instead of RM x X, and the frames of the previous point applied once per interval.
+template <class M, int RM, bool PBJ = false>
 __global__ void __launch_bounds__(64, CHMC_LEAN_WAVES) k_newton_lean(Sys sy, Slots sl, Work w, int which, int qsel) {
   constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0;
+  constexpr int NJP = PBJ ? X * V : RM * V, NY = PBJ ? X * X : RM * X;
   static_assert(RM <= 8, "blocks of at most 8 rows");
-  __shared__ double LamF[RM * X], Dl[RM * RM], zl[RM * Z], Ys[RM * X], Ws[X * Z];
+  __shared__ double LamF[RM * X], Dl[RM * RM], zl[RM * Z], Ys[RM * X], Ws[X * Z], Ss[X * X];
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x;
   if (wid >= sy.B * sy.K) return;
@@ -698,6 +725,8 @@ __global__ void __launch_bounds__(64, CHMC_LEAN_WAVES) k_newton_lean(Sys sy, Slo
   const double* q = (qsel ? w.qb : pick(sl.q, sl_ ^ 1)) + (size_t)c * sy.Q;
   const double* traj = w.trajw + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
   const double* Jr = pick(sl.Jv, sl_) + (size_t)c * RM * NV;
+  const double* PBr = PBJ ? pick(sl.PB, sl_) + ((size_t)c * sy.T * S + bd.step0) * (X * V) : nullptr;
+  const double* LFr = PBJ ? pick(sl.LF, sl_) + cb * sy.NOBS * RM * X : nullptr;
   ChainConsts<M> cc;
   cc.init(q, sy.dl);
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
@@ -710,22 +739,36 @@ __global__ void __launch_bounds__(64, CHMC_LEAN_WAVES) k_newton_lean(Sys sy, Slo
   for (int e = lane; e < RM * RM; e += 64) Dl[e] = 0.0;
   for (int e = lane; e < RM * Z; e += 64) zl[e] = 0.0;
   lds_sync();
-  double Wacc[X * Z], Yacc[RM * X], Pf[X * X];
+  double Wacc[X * Z], Yacc[NY], Pf[X * X];
 #pragma unroll
   for (int i = 0; i < X * Z; ++i) Wacc[i] = 0.0;
 #pragma unroll
-  for (int i = 0; i < RM * X; ++i) Yacc[i] = 0.0;
+  for (int i = 0; i < NY; ++i) Yacc[i] = 0.0;
 #pragma unroll
   for (int i = 0; i < X * X; ++i) Pf[i] = (i / X == i % X) ? 1.0 : 0.0;
   // end of an interval: the wave's sums, the RM-sized products (one lane per entry), the rows at the interval's start
-  auto flush_frame = [&]() {
+  // (jprev: the interval that has just been swept; bd.nobs when nothing has been swept yet)
+  auto flush_frame = [&](int jprev) {
 #pragma unroll
-    for (int i = 0; i < RM * X; ++i) {
+    for (int i = 0; i < NY; ++i) {
       double v = Yacc[i];
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-      if (lane == i) Ys[i] = v;
+      if (lane == i) (PBJ ? Ss : Ys)[i] = v;
       Yacc[i] = 0.0;
+    }
+    if (PBJ) {  // Ys[jj][a] = sum_s T_s[a][:] . (dc_jj/dv_s of the stored point) = sum_a2 Ss[a][a2] LFprev[jj][a2]
+      lds_sync();
+      if (lane < RM * X) {
+        const int jj = lane / X, a = lane - jj * X;
+        double tt = 0.0;
+        if (jprev < bd.nobs) {
+          const double* lf = LFr + ((size_t)jprev * RM + jj) * X;
+#pragma unroll
+          for (int a2 = 0; a2 < X; ++a2) tt += Ss[a * X + a2] * lf[a2];
+        }
+        Ys[lane] = tt;
+      }
     }
 #pragma unroll
     for (int i = 0; i < X * Z; ++i) {
@@ -769,7 +812,7 @@ __global__ void __launch_bounds__(64, CHMC_LEAN_WAVES) k_newton_lean(Sys sy, Slo
   };
   const int ntile = (S + 63) >> 6;
   struct Raw {
-    double x[X], v[V], jp[RM * V];
+    double x[X], v[V], jp[NJP];
     bool valid;
   };
   auto fetch = [&](int tt, Raw& r) {
@@ -783,6 +826,10 @@ __global__ void __launch_bounds__(64, CHMC_LEAN_WAVES) k_newton_lean(Sys sy, Slo
 #pragma unroll
       for (int a = 0; a < V; ++a) r.v[a] = vbase[(size_t)s * V + a];
       const size_t col = colb + (size_t)s * V;
+      if constexpr (PBJ) {
+#pragma unroll
+        for (int k = 0; k < X * V; ++k) r.jp[k] = ld_stream(PBr + (size_t)s * (X * V) + k);
+      } else
       // Observation row i is structurally zero in the intervals after its own (jj > i): those entries are zeros in HBM.
       // Branching around their loads would break the load pipelining, so the loads stay and are pointed at a small block
       // of zeros that lives in the caches: same instructions, 2 of 7 rows' bytes less HBM traffic.
@@ -802,7 +849,7 @@ __global__ void __launch_bounds__(64, CHMC_LEAN_WAVES) k_newton_lean(Sys sy, Slo
 #pragma unroll
       for (int a = 0; a < V; ++a) r.v[a] = 0.0;
 #pragma unroll
-      for (int i = 0; i < RM * V; ++i) r.jp[i] = 0.0;
+      for (int i = 0; i < NJP; ++i) r.jp[i] = 0.0;
     }
   };
   Raw r0, r1;
@@ -811,7 +858,7 @@ __global__ void __launch_bounds__(64, CHMC_LEAN_WAVES) k_newton_lean(Sys sy, Slo
     const int j = tt / ntile, t = tt - j * ntile;
     fetch(tt - 1, r1);
     if (t == ntile - 1) {
-      flush_frame();  // the interval that has just been swept
+      flush_frame(j + 1);  // the interval that has just been swept
       // rows that start at the end of observation interval j
       if (j < bd.ny) {
         double g[X], gl = 0.0;
@@ -861,15 +908,27 @@ __global__ void __launch_bounds__(64, CHMC_LEAN_WAVES) k_newton_lean(Sys sy, Slo
         for (int e = 0; e < X; ++e) tt2 += PE[a * X + e] * Zf[e * Z + mz];
         Wacc[a * Z + mz] = tt2;
       }
+    if constexpr (PBJ) {
 #pragma unroll
-    for (int jj = 0; jj < RM; ++jj)
+      for (int a = 0; a < X; ++a)
 #pragma unroll
-      for (int a = 0; a < X; ++a) {
-        double tt2 = Yacc[jj * X + a];
+        for (int a2 = 0; a2 < X; ++a2) {
+          double tt2 = Yacc[a * X + a2];
 #pragma unroll
-        for (int d = 0; d < V; ++d) tt2 += T[a * V + d] * r0.jp[jj * V + d];
-        Yacc[jj * X + a] = tt2;
-      }
+          for (int d = 0; d < V; ++d) tt2 += T[a * V + d] * r0.jp[a2 * V + d];
+          Yacc[a * X + a2] = tt2;
+        }
+    } else {
+#pragma unroll
+      for (int jj = 0; jj < RM; ++jj)
+#pragma unroll
+        for (int a = 0; a < X; ++a) {
+          double tt2 = Yacc[jj * X + a];
+#pragma unroll
+          for (int d = 0; d < V; ++d) tt2 += T[a * V + d] * r0.jp[jj * V + d];
+          Yacc[jj * X + a] = tt2;
+        }
+    }
     {
       double Pn[X * X];
       matmul_xx<X>(Pf, I0, Pn);
@@ -878,7 +937,7 @@ __global__ void __launch_bounds__(64, CHMC_LEAN_WAVES) k_newton_lean(Sys sy, Slo
     }
     r0 = r1;
   }
-  flush_frame();  // the first interval; LamF now holds the rows at the start of the block
+  flush_frame(0);  // the first interval; LamF now holds the rows at the start of the block
   // x_0 = generate_x_0(z, v_0): the v_0 columns and the z-dependence of the first block
   if (bd.first) {
     double dz[X * Z], dv0[X * V0];
