@@ -104,6 +104,7 @@ struct Slots {
 
 struct Work {
   double* muF;      // [B][Kmax][NOBS][X]  sum_i lambda_i LF[m][i]: the multipliers applied to the interval frames
+  double* muF2;     //                     the same for lampad2 (two-vector projection)
   double* trajw;    // [B][TRJ]      trajectory of the Newton iterate
   double* cpad;     // [B][Kmax][RM] constraint values, block-padded
   double* cpad2;    // [B][Kmax][RM] second right-hand side of a two-vector projection
@@ -1513,11 +1514,13 @@ struct KUpdate {
   }
 };
 
-// J^T lambda of a Newton / quasi-Newton iteration from the compact rows (Slots::PB, Slots::LF):
-//   KMuF      muF[c][b][m] = sum_i lambda_i LF[m][i]                       (one work item per entry, tiny)
-//   KUpdatePB q_v[s] -= muF[m(s)] . PB[s] for every step s, max |delta| per chain; the v_0 and observation-noise columns
-//             as in KUpdate (from the stored rows / sigma lambda).  Column-max launch over T S + V0 + (noisy ? T : 0) items.
-template <int RM, int X>
+// J^T lambda from the compact rows (Slots::PB, Slots::LF), the counterpart of KUpdate<RM, TGT, .>:
+//   KMuF      muF[c][b][m] = sum_i lambda_i LF[m][i]   (TGT 3: muF2 from lampad2 as well; one work item per entry, tiny)
+//   KUpdatePB target_v[s] -= muF[m(s)] . PB[s] for every step s; the v_0 and observation-noise columns as in KUpdate
+//             (from the stored rows / sigma lambda).  Column-max launch over T S + V0 + (noisy ? T : 0) items.
+//   TGT 0: Newton / quasi-Newton position update with max |delta| per chain;  TGT 1: a momentum-like vector (psel);
+//   TGT 3: p (multipliers lampad2) and pg (multipliers lampad) in one pass.
+template <int RM, int X, int TGT>
 struct KMuF {
   Sys sy;
   Slots sl;
@@ -1529,47 +1532,63 @@ struct KMuF {
     const int m = r % sy.NOBS;
     r /= sy.NOBS;
     const int b = r % sy.K, c = r / sy.K;
-    if (w.nw[c] != 1) return;
+    if (TGT == 0 ? w.nw[c] != 1 : !w.ok[c]) return;
     const size_t cb = (size_t)c * sy.Kmax + b;
-    double t = 0.0;
+    double t = 0.0, t2 = 0.0;
     if (m < sy.blk[b].nobs) {
       const double* lam = w.lampad + cb * RM;
+      const double* lam2 = w.lampad2 + cb * RM;
       const double* lf = pick(sl.LF, sl.cur[c] ^ which) + (cb * sy.NOBS + m) * RM * X;
       const int nr = sy.blk[b].nrows;
       for (int i = 0; i < RM; ++i)
-        if (i < nr) t += lam[i] * lf[i * X + a];
+        if (i < nr) {
+          t += lam[i] * lf[i * X + a];
+          if (TGT == 3) t2 += lam2[i] * lf[i * X + a];
+        }
     }
     w.muF[(cb * sy.NOBS + m) * X + a] = t;
+    if (TGT == 3) w.muF2[(cb * sy.NOBS + m) * X + a] = t2;
   }
 };
-template <int RM, int X, int V>
+template <int RM, int X, int V, int TGT>
 struct KUpdatePB {
   Sys sy;
   Slots sl;
   Work w;
-  int which, qsel;
-  CHMC_HD bool active(int c) const { return w.nw[c] == 1; }
-  CHMC_HD unsigned long long* red(int c) const { return &w.ndq[c]; }
+  int which, qsel, psel;
+  CHMC_HD bool active(int c) const { return TGT == 0 ? w.nw[c] == 1 : w.ok[c] != 0; }
+  CHMC_HD unsigned long long* red(int c) const { return TGT == 0 ? &w.ndq[c] : nullptr; }
   CHMC_HD unsigned long long operator()(int c, int idx) const {
     const int s = sl.cur[c] ^ which;
-    double* tgt = (qsel ? w.qb : pick(sl.q, s ^ 1)) + (size_t)c * sy.Q + sy.U;
+    const size_t off = (size_t)c * sy.Q + sy.U;
+    double* tgt = (TGT == 0 ? (qsel ? w.qb : pick(sl.q, s ^ 1))
+                            : TGT == 1 ? (psel == 0 ? pick(sl.p, s) : psel == 1 ? w.pb : psel == 3 ? pick(sl.pg, s) : pick(sl.p, s ^ 1))
+                                       : pick(sl.pg, s)) + off;
+    double* tgt2 = TGT == 3 ? pick(sl.p, s) + off : nullptr;  // TGT 3: p with the multipliers lampad2
     const int TS = sy.T * sy.S;
     unsigned long long r = 0ULL;
     if (idx < TS) {
       const int g = idx / sy.S;  // observation interval
       const int b = sy.obs2blk[g];
       const int m = g - sy.blk[b].obs0;
-      const double* mu = w.muF + (((size_t)c * sy.Kmax + b) * sy.NOBS + m) * X;
+      const size_t mo = (((size_t)c * sy.Kmax + b) * sy.NOBS + m) * X;
       const double* pb = pick(sl.PB, s) + ((size_t)c * TS + idx) * (X * V);
-      double* t = tgt + sy.V0 + (size_t)idx * V;
+      const size_t to = sy.V0 + (size_t)idx * V;
       const bool wide = V == 2 && !((sy.Q | sy.U | sy.V0) & 1);
-      double old[V], pbv[X * V], d[V];
+      double old[V], old2[V], pbv[X * V];
       if (wide) {
-        const double2_ o = *reinterpret_cast<const double2_*>(t);
+        const double2_ o = *reinterpret_cast<const double2_*>(tgt + to);
         old[0] = o.x, old[V - 1] = o.y;
+        if (TGT == 3) {
+          const double2_ o2 = *reinterpret_cast<const double2_*>(tgt2 + to);
+          old2[0] = o2.x, old2[V - 1] = o2.y;
+        }
       } else {
         CHMC_UNROLL
-        for (int k = 0; k < V; ++k) old[k] = t[k];
+        for (int k = 0; k < V; ++k) {
+          old[k] = tgt[to + k];
+          if (TGT == 3) old2[k] = tgt2[to + k];
+        }
       }
       if ((X * V) % 2 == 0) {
         CHMC_UNROLL
@@ -1583,44 +1602,65 @@ struct KUpdatePB {
       }
       CHMC_UNROLL
       for (int k = 0; k < V; ++k) {
-        double tt = 0.0;
+        double tt = 0.0, t2 = 0.0;
         CHMC_UNROLL
-        for (int a = 0; a < X; ++a) tt += mu[a] * pbv[a * V + k];
-        d[k] = tt;
-        const unsigned long long vb = absbits(tt);
-        r = vb > r ? vb : r;
+        for (int a = 0; a < X; ++a) {
+          tt += w.muF[mo + a] * pbv[a * V + k];
+          if (TGT == 3) t2 += w.muF2[mo + a] * pbv[a * V + k];
+        }
+        if (TGT == 0) {
+          const unsigned long long vb = absbits(tt);
+          r = vb > r ? vb : r;
+        }
         old[k] -= tt;
+        if (TGT == 3) old2[k] -= t2;
       }
       if (wide) {
         double2_ o;
         o.x = old[0], o.y = old[V - 1];
-        *reinterpret_cast<double2_*>(t) = o;
+        *reinterpret_cast<double2_*>(tgt + to) = o;
+        if (TGT == 3) {
+          o.x = old2[0], o.y = old2[V - 1];
+          *reinterpret_cast<double2_*>(tgt2 + to) = o;
+        }
       } else {
         CHMC_UNROLL
-        for (int k = 0; k < V; ++k) t[k] = old[k];
+        for (int k = 0; k < V; ++k) {
+          tgt[to + k] = old[k];
+          if (TGT == 3) tgt2[to + k] = old2[k];
+        }
       }
     } else {
       const int e = idx - TS;
-      double d;
+      double d = 0.0, d2 = 0.0;
       int col;
       if (e < sy.V0) {  // v_0 columns: the first block's stored rows
         col = e;
         const int b = sy.obs2blk[0];
         const double* lam = w.lampad + ((size_t)c * sy.Kmax + b) * RM;
+        const double* lam2 = w.lampad2 + ((size_t)c * sy.Kmax + b) * RM;
         const double* Jv = pick(sl.Jv, s) + (size_t)c * RM * sy.NV + col;
         const int nr = sy.blk[b].nrows;
-        d = 0.0;
         for (int i = 0; i < RM; ++i)
-          if (i < nr) d += Jv[(size_t)i * sy.NV] * lam[i];
+          if (i < nr) {
+            const double jv = Jv[(size_t)i * sy.NV];
+            d += jv * lam[i];
+            if (TGT == 3) d2 += jv * lam2[i];
+          }
       } else {  // observation-noise columns: dc/dn = sigma on the y rows (:601-608)
         const int t = e - sy.V0;
         col = sy.NV + t;
         const int b = sy.obs2blk[t];
         const int j = t - sy.blk[b].obs0;
-        d = j < sy.blk[b].ny ? sigma_at(sy, pick(sl.q, s) + (size_t)c * sy.Q) * w.lampad[((size_t)c * sy.Kmax + b) * RM + j] : 0.0;
+        if (j < sy.blk[b].ny) {
+          const double sg = sigma_at(sy, pick(sl.q, s) + (size_t)c * sy.Q);
+          d = sg * w.lampad[((size_t)c * sy.Kmax + b) * RM + j];
+          if (TGT == 3) d2 = sg * w.lampad2[((size_t)c * sy.Kmax + b) * RM + j];
+        }
       }
-      r = absbits(d);
+      if (TGT == 0) r = absbits(d);
       tgt[col] -= d;
+      if (TGT == 3) tgt2[col] -= d2;
     }
     return r;
   }

@@ -1540,6 +1540,121 @@ __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int w
   }
 }
 
+// J w from the compact rows (Slots::PB / LF), same interface and result arrays as k_jw_wave: inside observation
+// interval m the rows are LF[m][i] . PB[s], so the pass accumulates the row-independent y_m = sum_s PB[s] w_s (X values
+// per lane) and applies the frame once per interval: X V doubles of rows per step instead of up to RM V.
+template <int RM, int X, int V, bool TWO = false>
+__global__ void __launch_bounds__(256) k_jw_pb(Sys sy, Slots sl, Work w, int which, int vsel_) {
+  const bool minv = (vsel_ & 256) != 0;
+  const int vsel = vsel_ & 255;
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (wid >= sy.B * sy.K) return;
+  const int cbi = sy.order[wid];  // work order: longest blocks first
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (!w.ok[c]) return;
+  const BlockDesc bd = sy.blk[b];
+  const int s = sl.cur[c] ^ which;
+  const double* vct = (vsel == 0 ? pick(sl.p, s) : vsel == 1 ? w.pb : vsel == 2 ? w.vin : vsel == 4 ? pick(sl.pg, s) : pick(sl.p, s ^ 1)) + (size_t)c * sy.Q;
+  const double* vct2 = pick(sl.pg, s) + (size_t)c * sy.Q;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const double* PB = pick(sl.PB, s) + ((size_t)c * sy.T * sy.S + bd.step0) * (X * V);
+  const double* LF = pick(sl.LF, s) + cb * sy.NOBS * RM * X;
+  const double* wv = vct + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const double* wv2 = vct2 + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const bool wide = V == 2 && !((sy.Q | sy.U | sy.V0) & 1);
+  double acc[RM], acc2[RM];
+#pragma unroll
+  for (int i = 0; i < RM; ++i) acc[i] = 0.0, acc2[i] = 0.0;
+  for (int m = 0; m < bd.nobs; ++m) {
+    double y[X], y2[X];
+#pragma unroll
+    for (int a = 0; a < X; ++a) y[a] = 0.0, y2[a] = 0.0;
+    for (int k = m * sy.S + lane; k < (m + 1) * sy.S; k += 64) {
+      double pb[X * V], x[V], x2[V];
+      const double* src = PB + (size_t)k * (X * V);
+      if ((X * V) % 2 == 0) {
+#pragma unroll
+        for (int e = 0; e < X * V; e += 2) {
+          const double2_ v = ld2_stream(src + e);
+          pb[e] = v.x, pb[e + 1 < X * V ? e + 1 : e] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < X * V; ++e) pb[e] = ld_stream(src + e);
+      }
+      if (wide) {
+        const double2_ v = *reinterpret_cast<const double2_*>(wv + (size_t)k * V);
+        x[0] = v.x, x[V - 1] = v.y;
+        if (TWO) {
+          const double2_ v2 = *reinterpret_cast<const double2_*>(wv2 + (size_t)k * V);
+          x2[0] = v2.x, x2[V - 1] = v2.y;
+        }
+      } else {
+#pragma unroll
+        for (int d = 0; d < V; ++d) x[d] = wv[(size_t)k * V + d], x2[d] = TWO ? wv2[(size_t)k * V + d] : 0.0;
+      }
+#pragma unroll
+      for (int a = 0; a < X; ++a)
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          y[a] += pb[a * V + d] * x[d];
+          if (TWO) y2[a] += pb[a * V + d] * x2[d];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < X; ++a) {
+      double v = y[a];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+      y[a] = v;
+      if (TWO) {
+        v = y2[a];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        y2[a] = v;
+      }
+    }
+    const double* lf = LF + (size_t)m * RM * X;
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+      for (int a = 0; a < X; ++a) {
+        const double f = lf[i * X + a];
+        acc[i] += f * y[a];
+        if (TWO) acc2[i] += f * y2[a];
+      }
+  }
+  if (lane < RM) {
+    const int i = lane;
+    double a = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < RM; ++k)
+      if (k == i) a = acc[k], a2 = acc2[k];
+    if (i < bd.nrows) {
+      if (bd.first) {  // v_0 columns: from the stored rows
+        const double* Jv = pick(sl.Jv, s) + (size_t)c * RM * sy.NV + (size_t)i * sy.NV;
+        for (int d = 0; d < sy.V0; ++d) {
+          a += Jv[d] * vct[sy.U + d];
+          if (TWO) a2 += Jv[d] * vct2[sy.U + d];
+        }
+      }
+      const double* ju = pick(sl.JuP, s) + (cb * RM + i) * sy.U;
+      for (int d = 0; d < sy.U; ++d) a += ju[d] * (minv ? metric_inv_u(sy, vct, d) : vct[d]);
+      const double sg = sy.noisy ? sigma_at(sy, pick(sl.q, s) + (size_t)c * sy.Q) : 0.0;
+      if (sy.noisy && i < bd.ny) a += sg * vct[sy.U + sy.NV + bd.obs0 + i];
+      if (TWO) {
+        for (int d = 0; d < sy.U; ++d) a2 += ju[d] * (minv ? metric_inv_u(sy, vct2, d) : vct2[d]);
+        if (sy.noisy && i < bd.ny) a2 += sg * vct2[sy.U + sy.NV + bd.obs0 + i];
+      }
+    } else {
+      a = 0.0, a2 = 0.0;
+    }
+    w.cpad[cb * RM + i] = a;
+    if (TWO) w.cpad2[cb * RM + i] = a2;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Gradient of 1/2 log det Gram (value_and_grad of log_det_sqrt_gram, :812-820, :1143-1146), wave per (chain, block).
 // Same mathematics as KGldBlk (chmc_core.h); the two sweeps are wave-level scans over 64-step tiles:
