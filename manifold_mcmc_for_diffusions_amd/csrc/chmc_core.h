@@ -1550,8 +1550,8 @@ struct KMuF {
     if (TGT == 3) w.muF2[(cb * sy.NOBS + m) * X + a] = t2;
   }
 };
-template <int RM, int X, int V, int TGT>
-struct KUpdatePB {
+template <int RM, int X, int V, int TGT, int NS = 1>
+struct KUpdatePB {  // NS: consecutive steps per work item (2 when S is even: both lie in the same observation interval)
   Sys sy;
   Slots sl;
   Work w;
@@ -1567,71 +1567,86 @@ struct KUpdatePB {
     double* tgt2 = TGT == 3 ? pick(sl.p, s) + off : nullptr;  // TGT 3: p with the multipliers lampad2
     const int TS = sy.T * sy.S;
     unsigned long long r = 0ULL;
-    if (idx < TS) {
-      const int g = idx / sy.S;  // observation interval
+    if (idx < TS / NS) {
+      const int st0 = idx * NS;
+      const int g = st0 / sy.S;  // observation interval
       const int b = sy.obs2blk[g];
       const int m = g - sy.blk[b].obs0;
       const size_t mo = (((size_t)c * sy.Kmax + b) * sy.NOBS + m) * X;
-      const double* pb = pick(sl.PB, s) + ((size_t)c * TS + idx) * (X * V);
-      const size_t to = sy.V0 + (size_t)idx * V;
+      const double* pb = pick(sl.PB, s) + ((size_t)c * TS + st0) * (X * V);
+      const size_t to = sy.V0 + (size_t)st0 * V;
       const bool wide = V == 2 && !((sy.Q | sy.U | sy.V0) & 1);
-      double old[V], old2[V], pbv[X * V];
-      if (wide) {
-        const double2_ o = *reinterpret_cast<const double2_*>(tgt + to);
-        old[0] = o.x, old[V - 1] = o.y;
-        if (TGT == 3) {
-          const double2_ o2 = *reinterpret_cast<const double2_*>(tgt2 + to);
-          old2[0] = o2.x, old2[V - 1] = o2.y;
-        }
-      } else {
-        CHMC_UNROLL
-        for (int k = 0; k < V; ++k) {
-          old[k] = tgt[to + k];
-          if (TGT == 3) old2[k] = tgt2[to + k];
+      double old[NS * V], old2[NS * V], pbv[NS * X * V], mu[X], mu2[X];
+      // all loads first: the work item's bytes in flight hide the memory latency
+      CHMC_UNROLL
+      for (int e = 0; e < NS; ++e) {
+        if (wide) {
+          const double2_ o = *reinterpret_cast<const double2_*>(tgt + to + e * V);
+          old[e * V] = o.x, old[e * V + V - 1] = o.y;
+          if (TGT == 3) {
+            const double2_ o2 = *reinterpret_cast<const double2_*>(tgt2 + to + e * V);
+            old2[e * V] = o2.x, old2[e * V + V - 1] = o2.y;
+          }
+        } else {
+          CHMC_UNROLL
+          for (int k = 0; k < V; ++k) {
+            old[e * V + k] = tgt[to + e * V + k];
+            if (TGT == 3) old2[e * V + k] = tgt2[to + e * V + k];
+          }
         }
       }
-      if ((X * V) % 2 == 0) {
+      if ((NS * X * V) % 2 == 0) {
         CHMC_UNROLL
-        for (int k = 0; k < X * V; k += 2) {
+        for (int k = 0; k < NS * X * V; k += 2) {
           const double2_ v = ld2_stream(pb + k);
-          pbv[k] = v.x, pbv[k + 1 < X * V ? k + 1 : k] = v.y;
+          pbv[k] = v.x, pbv[k + 1 < NS * X * V ? k + 1 : k] = v.y;
         }
       } else {
         CHMC_UNROLL
-        for (int k = 0; k < X * V; ++k) pbv[k] = pb[k];
+        for (int k = 0; k < NS * X * V; ++k) pbv[k] = pb[k];
       }
       CHMC_UNROLL
-      for (int k = 0; k < V; ++k) {
-        double tt = 0.0, t2 = 0.0;
-        CHMC_UNROLL
-        for (int a = 0; a < X; ++a) {
-          tt += w.muF[mo + a] * pbv[a * V + k];
-          if (TGT == 3) t2 += w.muF2[mo + a] * pbv[a * V + k];
-        }
-        if (TGT == 0) {
-          const unsigned long long vb = absbits(tt);
-          r = vb > r ? vb : r;
-        }
-        old[k] -= tt;
-        if (TGT == 3) old2[k] -= t2;
+      for (int a = 0; a < X; ++a) {
+        mu[a] = w.muF[mo + a];
+        if (TGT == 3) mu2[a] = w.muF2[mo + a];
       }
-      if (wide) {
-        double2_ o;
-        o.x = old[0], o.y = old[V - 1];
-        *reinterpret_cast<double2_*>(tgt + to) = o;
-        if (TGT == 3) {
-          o.x = old2[0], o.y = old2[V - 1];
-          *reinterpret_cast<double2_*>(tgt2 + to) = o;
-        }
-      } else {
+      CHMC_UNROLL
+      for (int e = 0; e < NS; ++e)
         CHMC_UNROLL
         for (int k = 0; k < V; ++k) {
-          tgt[to + k] = old[k];
-          if (TGT == 3) tgt2[to + k] = old2[k];
+          double tt = 0.0, t2 = 0.0;
+          CHMC_UNROLL
+          for (int a = 0; a < X; ++a) {
+            tt += mu[a] * pbv[e * X * V + a * V + k];
+            if (TGT == 3) t2 += mu2[a] * pbv[e * X * V + a * V + k];
+          }
+          if (TGT == 0) {
+            const unsigned long long vb = absbits(tt);
+            r = vb > r ? vb : r;
+          }
+          old[e * V + k] -= tt;
+          if (TGT == 3) old2[e * V + k] -= t2;
+        }
+      CHMC_UNROLL
+      for (int e = 0; e < NS; ++e) {
+        if (wide) {
+          double2_ o;
+          o.x = old[e * V], o.y = old[e * V + V - 1];
+          *reinterpret_cast<double2_*>(tgt + to + e * V) = o;
+          if (TGT == 3) {
+            o.x = old2[e * V], o.y = old2[e * V + V - 1];
+            *reinterpret_cast<double2_*>(tgt2 + to + e * V) = o;
+          }
+        } else {
+          CHMC_UNROLL
+          for (int k = 0; k < V; ++k) {
+            tgt[to + e * V + k] = old[e * V + k];
+            if (TGT == 3) tgt2[to + e * V + k] = old2[e * V + k];
+          }
         }
       }
     } else {
-      const int e = idx - TS;
+      const int e = idx - TS / NS;
       double d = 0.0, d2 = 0.0;
       int col;
       if (e < sy.V0) {  // v_0 columns: the first block's stored rows
