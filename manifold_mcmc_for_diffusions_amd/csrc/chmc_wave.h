@@ -1662,11 +1662,14 @@ __global__ void __launch_bounds__(256) k_jw_pb(Sys sy, Slots sl, Work w, int whi
 //   backward: adjoint rows Lam (matrix suffix scan, as k_rev_wave) and the summed second-order adjoint x-bar,
 //             a joint (matrix, vector) suffix scan with the Hessian contraction as the source term.
 // Tangents are stored component-major ([RM*X][T*S] per chain) so both sweeps stream them with unit stride.
-template <class M, int RM>
+// PBJ (both sweeps): the stored rows are read in their compact form (Slots::PB / LF).  The weights w_i = sum_jj
+// (G^-1)_i,jj dc_jj/dv_s are then  MLF[m][i] . PB[s]  with the per-interval RM x X matrix MLF[m] = (G^-1)_bb LF[m]
+// (wave-uniform, formed once per interval): X V doubles per step instead of RM V, RM X V multiply-adds instead of RM RM V.
+template <class M, int RM, bool PBJ = false>
 __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, int which) {
   constexpr int X = M::X, V = M::V, Z = M::Z, V0 = M::V0;
   constexpr int URM = 64;  // (the forward sweep is correct fully unrolled at 16 rows as well; the backward sweep is not, see there)
-  __shared__ double sm[4][RM * RM + RM * Z];
+  __shared__ double sm[4][RM * RM + RM * Z + (PBJ ? RM * X : 0)];
   const int lane = threadIdx.x & 63;
   const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wid = blockIdx.x * (blockDim.x >> 6) + wv_;
@@ -1687,12 +1690,16 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
   double* Xd = w.Xd + (size_t)c * RM * X * TS + bd.step0;
   double* Mb = sm[wv_];
   double* zd = sm[wv_] + RM * RM;
+  double* MLFs = sm[wv_] + RM * RM + RM * Z;
+  const double* PBr = PBJ ? pick(sl.PB, s_) + ((size_t)c * TS + bd.step0) * (X * V) : nullptr;
+  const double* LFr = PBJ ? pick(sl.LF, s_) + cb * sy.NOBS * RM * X : nullptr;
   for (int i = lane; i < RM * RM; i += 64) Mb[i] = w.gMb[cb * RM * RM + i];
   for (int i = lane; i < RM * Z; i += 64) zd[i] = w.gzd[cb * RM * Z + i];
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   ChainConsts<M> cc;
   cc.init(q, sy.dl);
+  double mlf[PBJ ? RM * X : 1];
   double xdc[RM * X];  // tangents at the start of the current tile (wave-uniform)
 #pragma unroll URM
   for (int i = 0; i < RM * X; ++i) xdc[i] = 0.0;
@@ -1713,13 +1720,27 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
   }
   const int ntile = (S + 63) >> 6;
   for (int j = 0; j < bd.nobs; ++j) {
+    if constexpr (PBJ) {  // MLF[j] = (G^-1)_bb LF[j], one entry per lane, then to every lane's registers
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      if (lane < RM * X) {
+        const int i = lane / X, a = lane - i * X;
+        double t = 0.0;
+        for (int jj = 0; jj < RM; ++jj) t += Mb[i * RM + jj] * LFr[((size_t)j * RM + jj) * X + a];
+        MLFs[lane] = t;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int e2 = 0; e2 < RM * X; ++e2) mlf[e2] = MLFs[e2];
+    }
     for (int t = 0; t < ntile; ++t) {
       const int off = (t << 6) + lane;
       const bool valid = off < S;
       const int s = j * S + off;
       double P[X * X], e[RM * X];
       {
-        double A[X * X], Bm[X * V], Zf[X * Z], jp[RM * V];
+        double A[X * X], Bm[X * V], Zf[X * Z], jp[PBJ ? X * V : RM * V];
         if (valid) {
           double x[X], vv[V];
 #pragma unroll
@@ -1728,6 +1749,10 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
           for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
           M::jac(cc.k, x, vv, A, Bm, Zf);
           const size_t col = colb + (size_t)s * V;
+          if constexpr (PBJ) {
+#pragma unroll
+            for (int k = 0; k < X * V; ++k) jp[k] = ld_stream(PBr + (size_t)s * (X * V) + k);
+          } else
           // rows i < j (their observation lies before this interval) and padded slots are structurally zero
 #pragma unroll URM
           for (int i = 0; i < RM; ++i) {
@@ -1743,7 +1768,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
 #pragma unroll
           for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
 #pragma unroll URM
-          for (int i = 0; i < RM * V; ++i) jp[i] = 0.0;
+          for (int i = 0; i < (PBJ ? X * V : RM * V); ++i) jp[i] = 0.0;
         }
 #pragma unroll
         for (int i = 0; i < X * X; ++i) P[i] = A[i];
@@ -1753,8 +1778,13 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
 #pragma unroll
           for (int d = 0; d < V; ++d) {
             double tt = 0.0;
+            if constexpr (PBJ) {
+#pragma unroll
+              for (int a = 0; a < X; ++a) tt += mlf[i * X + a] * jp[a * V + d];
+            } else {
 #pragma unroll URM
-            for (int jj = 0; jj < RM; ++jj) tt += Mb[i * RM + jj] * jp[jj * V + d];
+              for (int jj = 0; jj < RM; ++jj) tt += Mb[i * RM + jj] * jp[jj * V + d];
+            }
             wv[d] = tt;
           }
 #pragma unroll
@@ -1852,7 +1882,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
   }
 }
 
-template <class M, int RM>
+template <class M, int RM, bool PBJ = false>
 __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, int which) {
   constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0, NXI = M::NXI;
 #ifdef CHMC_GLD_BWD_URM16
@@ -1860,7 +1890,7 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
 #else
   constexpr int URM = RM <= 8 ? 64 : 1;
 #endif
-  __shared__ double sm[4][RM * RM + RM * Z];
+  __shared__ double sm[4][RM * RM + RM * Z + (PBJ ? RM * X : 0)];
   const int lane = threadIdx.x & 63;
   const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wid = blockIdx.x * (blockDim.x >> 6) + wv_;
@@ -1882,6 +1912,10 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
   double* gv = pick(sl.grad, s_) + (size_t)c * sy.Q + sy.U;
   double* Mb = sm[wv_];
   double* zd = sm[wv_] + RM * RM;
+  double* MLFs = sm[wv_] + RM * RM + RM * Z;
+  const double* PBr = PBJ ? pick(sl.PB, s_) + ((size_t)c * TS + bd.step0) * (X * V) : nullptr;
+  const double* LFr = PBJ ? pick(sl.LF, s_) + cb * sy.NOBS * RM * X : nullptr;
+  double mlf[PBJ ? RM * X : 1];
   for (int i = lane; i < RM * RM; i += 64) Mb[i] = w.gMb[cb * RM * RM + i];
   for (int i = lane; i < RM * Z; i += 64) zd[i] = w.gzd[cb * RM * Z + i];
   __builtin_amdgcn_wave_barrier();
@@ -1917,6 +1951,20 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
         for (int a = 0; a < X; ++a)
           if (i == bd.ny + a) Lam[i * X + a] = 1.0;
     }
+    if constexpr (PBJ) {  // MLF[j] = (G^-1)_bb LF[j]
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      if (lane < RM * X) {
+        const int i = lane / X, a = lane - i * X;
+        double t2 = 0.0;
+        for (int jj = 0; jj < RM; ++jj) t2 += Mb[i * RM + jj] * LFr[((size_t)j * RM + jj) * X + a];
+        MLFs[lane] = t2;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int e2 = 0; e2 < RM * X; ++e2) mlf[e2] = MLFs[e2];
+    }
     for (int t = ntile - 1; t >= 0; --t) {
       const int off = (t << 6) + (63 - lane);  // LATER steps in LOWER lanes: the suffix scans become DPP prefix scans
       const bool valid = off < S;
@@ -1950,12 +1998,17 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
         double Sm[X * NXI];
 #pragma unroll
         for (int i = 0; i < X * NXI; ++i) Sm[i] = 0.0;
-        double jp[RM * V];
-#pragma unroll URM
-        for (int i = 0; i < RM; ++i) {
-          const bool act = valid && i >= j && i < bd.nrows;
+        double jp[PBJ ? X * V : RM * V];
+        if constexpr (PBJ) {
 #pragma unroll
-          for (int d = 0; d < V; ++d) jp[i * V + d] = act ? Jv[(size_t)i * NV + col + d] : 0.0;
+          for (int k = 0; k < X * V; ++k) jp[k] = valid ? ld_stream(PBr + (size_t)s * (X * V) + k) : 0.0;
+        } else {
+#pragma unroll URM
+          for (int i = 0; i < RM; ++i) {
+            const bool act = valid && i >= j && i < bd.nrows;
+#pragma unroll
+            for (int d = 0; d < V; ++d) jp[i * V + d] = act ? Jv[(size_t)i * NV + col + d] : 0.0;
+          }
         }
 #pragma unroll URM
         for (int i = 0; i < RM; ++i) {
@@ -1972,8 +2025,13 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, 
 #pragma unroll
           for (int d = 0; d < V; ++d) {
             double tt = 0.0;
+            if constexpr (PBJ) {
+#pragma unroll
+              for (int a = 0; a < X; ++a) tt += mlf[i * X + a] * jp[a * V + d];
+            } else {
 #pragma unroll URM
-            for (int jj = 0; jj < RM; ++jj) tt += Mb[i * RM + jj] * jp[jj * V + d];
+              for (int jj = 0; jj < RM; ++jj) tt += Mb[i * RM + jj] * jp[jj * V + d];
+            }
             dir[X + d] = tt;
           }
 #pragma unroll
