@@ -1514,6 +1514,36 @@ struct KUpdate {
   }
 };
 
+// The stored rows dc_i/dv_s = LF[m][i] . PB[s] of every chain's current state written out in full (Slots::Jv): only for
+// the per-operator entry points of the ABI that hand rows to the caller or run the row-based passes; the stepping path
+// works on the compact form and does not store the rows of the step columns at all.
+template <int RM, int X, int V>
+struct KRowsFromPB {
+  Sys sy;
+  Slots sl;
+  CHMC_HD void operator()(int tid) const {
+    const int TS = sy.T * sy.S;
+    const int c = tid / TS, st = tid - c * TS;
+    const int s = sl.cur[c];
+    const int g = st / sy.S;
+    const int b = sy.obs2blk[g];
+    const int m = g - sy.blk[b].obs0;
+    const double* lf = pick(sl.LF, s) + ((((size_t)c * sy.Kmax + b) * sy.NOBS + m) * RM) * X;
+    const double* pb = pick(sl.PB, s) + ((size_t)c * TS + st) * (X * V);
+    double* Jv = pick(sl.Jv, s) + (size_t)c * RM * sy.NV + sy.V0 + (size_t)st * V;
+    double pbv[X * V];
+    CHMC_UNROLL
+    for (int k = 0; k < X * V; ++k) pbv[k] = pb[k];
+    for (int i = 0; i < RM; ++i)
+      CHMC_UNROLL
+      for (int d = 0; d < V; ++d) {
+        double t = 0.0;
+        CHMC_UNROLL
+        for (int a = 0; a < X; ++a) t += lf[i * X + a] * pbv[a * V + d];
+        Jv[(size_t)i * sy.NV + d] = t;
+      }
+  }
+};
 // J^T lambda from the compact rows (Slots::PB, Slots::LF), the counterpart of KUpdate<RM, TGT, .>:
 //   KMuF      muF[c][b][m] = sum_i lambda_i LF[m][i]   (TGT 3: muF2 from lampad2 as well; one work item per entry, tiny)
 //   KUpdatePB target_v[s] -= muF[m(s)] . PB[s] for every step s; the v_0 and observation-noise columns as in KUpdate

@@ -241,6 +241,8 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
       LFo = pick(sl.LF, sl_) + cb * sy.NOBS * RM * X;
     }
   }
+  // MODE 0, qsel bit 1: the compact form only -- the rows of the step columns are not written (the v_0 columns are)
+  const bool store_rows = !(MODE == 0 && PBo && (qsel & 2));
   ChainConsts<M> cc;
   cc.init(q, sy.dl);
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
@@ -436,6 +438,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
               for (int k = 0; k < X * V; ++k) st_async(dst + k, T[k]);
             }
           }
+          if (store_rows)
 #pragma unroll
           for (int i = 0; i < RM; ++i) {
             double jr0[V];

@@ -1,6 +1,6 @@
 R=$PWD
 mkdir -p gpurun_out/r02t
-python -m pytest tests/test_hip_parity.py tests/test_golden.py -m gpu -x -q -k "not halves" 2>&1 | tail -3
+python -m pytest tests/test_hip_parity.py tests/test_golden.py tests/test_hip_surface.py -m gpu -x -q -k "not halves and not posterior" 2>&1 | tail -3
 for i in 1 2; do for lib in libchmc_hip.so libchmc_hip_prev.so; do
 CHMC_HIP_LIBRARY=$R/manifold_mcmc_for_diffusions_amd/$lib python bench.py --no-cpu-baseline > gpurun_out/r02t/b_$lib.$i.json 2>/dev/null
 python - $lib $i <<'PY'
