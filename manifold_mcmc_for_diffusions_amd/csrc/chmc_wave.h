@@ -707,10 +707,16 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
 #ifndef CHMC_LEAN_WAVES
 #define CHMC_LEAN_WAVES 2
 #endif
+// With the compact rows (PBJ) the FitzHugh-Nagumo instantiations need 188 VGPRs; capped at 168 (three wavefronts per
+// SIMD) they spill 13 dwords and still run 7 % faster (newton_blk 1.31 -> 1.21 ms per step).
+#ifndef CHMC_LEAN_WAVES_PB
+#define CHMC_LEAN_WAVES_PB 3
+#endif
 // PBJ: the previous point's rows are read in their compact form (Slots::PB / LF): X V doubles per step instead of RM V,
 // an X x X running sum instead of RM x X, and the frames of the previous point applied once per interval.
 template <class M, int RM, bool PBJ = false>
-__global__ void __launch_bounds__(64, CHMC_LEAN_WAVES) k_newton_lean(Sys sy, Slots sl, Work w, int which, int qsel) {
+__global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVES_PB : CHMC_LEAN_WAVES)
+    k_newton_lean(Sys sy, Slots sl, Work w, int which, int qsel) {
   constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0;
   constexpr int NJP = PBJ ? X * V : RM * V, NY = PBJ ? X * X : RM * X;
   static_assert(RM <= 8, "blocks of at most 8 rows");
@@ -1885,8 +1891,12 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
   }
 }
 
+// (two wavefronts per SIMD for the backward sweep: 256 VGPRs + 344 bytes of scratch, 1.07 -> 1.80 ms per step: not used)
+#ifndef CHMC_GLD_BWD_WAVES
+#define CHMC_GLD_BWD_WAVES 1
+#endif
 template <class M, int RM, bool PBJ = false>
-__global__ void __launch_bounds__(256) k_gld_bwd_wave(Sys sy, Slots sl, Work w, int which) {
+__global__ void __launch_bounds__(PBJ && CHMC_GLD_BWD_WAVES > 1 ? 64 : 256, PBJ ? CHMC_GLD_BWD_WAVES : 1) k_gld_bwd_wave(Sys sy, Slots sl, Work w, int which) {
   constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0, NXI = M::NXI;
 #ifdef CHMC_GLD_BWD_URM16
   constexpr int URM = RM <= 8 ? 64 : CHMC_GLD_BWD_URM16;  // (experiments on the 16-row instantiation)

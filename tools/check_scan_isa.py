@@ -101,7 +101,7 @@ def check_kernel(name, body):
     return problems
 
 
-NO_SPILL = ("k_newton_leanINS_8FhnModel", "k_newton_leanINS_10FhnNbModel", "k_rev_waveINS_8FhnModelELi7E", "k_gld_fwd_waveINS_8FhnModelELi7E",
+NO_SPILL = ("k_newton_leanINS_8FhnModelELi7ELb0", "k_rev_waveINS_8FhnModelELi7E", "k_gld_fwd_waveINS_8FhnModelELi7E",
             "k_gld_bwd_waveINS_8FhnModelELi7E")  # the hot instantiations of the headline configuration
 
 
