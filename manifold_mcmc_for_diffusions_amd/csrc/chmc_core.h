@@ -102,9 +102,17 @@ struct Slots {
   int* cur;
 };
 
+// Rounds a chain whose forward scan was handed to the side stream sits out before it re-joins its Newton loop (k_fwd_par,
+// run_projection).  The sequential scan of a 2 800-step chain takes 0.9 ms; with the two-phase sweep a round of the SIR
+// single-block loop takes 0.25-0.3 ms, so two rounds made the main stream wait for the side stream almost every time.
+// At most 3: four generations of flags (round & 3) are in flight.
+#ifndef CHMC_REJOIN
+#define CHMC_REJOIN 3
+#endif
 struct Work {
   double* muF;      // [B][Kmax][NOBS][X]  sum_i lambda_i LF[m][i]: the multipliers applied to the interval frames
   double* muF2;     //                     the same for lampad2 (two-vector projection)
+  double* ivl;      // [B][Kmax][NOBS][2 X X + X Z]  per-interval sums of the two-phase Newton sweep (k_newton_ivl)
   double* trajw;    // [B][TRJ]      trajectory of the Newton iterate
   double* cpad;     // [B][Kmax][RM] constraint values, block-padded
   double* cpad2;    // [B][Kmax][RM] second right-hand side of a two-vector projection

@@ -1003,6 +1003,280 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
   }
 }
 
+// The Newton-iteration sweep in two phases, for layouts with FEW, LONG blocks (SIR single block: B wavefronts of
+// k_newton_lean would each walk the whole chain, 300 us of pure latency per launch however few chains are active).
+// With the compact rows nothing in the hot loop depends on the adjoint rows, so the observation intervals of a block
+// are independent up to three small matrices each:
+//   phase A  k_newton_ivl : one wavefront per (chain, block, INTERVAL m): the wave's sums over the interval's steps
+//            Ss[m] = sum_s T_s PBprev_s^T (X x X),  Ws[m] = sum_s PE_s Zf_s (X x Z),  and the product Pt[m] of the
+//            interval's transition matrices (T_s = PE_s B_s, PE_s = product of the later transition matrices of the
+//            interval) -> work.ivl;
+//   phase B  k_newton_comb: one wavefront per (chain, block) walks the intervals backwards with everything RM-sized in
+//            LDS -- frame LamF[m] = rows injected at the interval's end + LamF[m+1] Pt[m+1];
+//            Gram += LamF[m] Ss[m] LFprev[m]^T;  dc/dz rows += LamF[m] Ws[m] -- and finishes as k_newton_lean does
+//            (v_0 columns, observation-noise diagonal, identity padding, dc/du rows through generate_z').
+// Any RM <= 16: no per-lane array is indexed by the row.
+#define CHMC_IVL_N(X, Z) (2 * (X) * (X) + (X) * (Z))
+template <class M>
+__global__ void __launch_bounds__(64, 2) k_newton_ivl(Sys sy, Slots sl, Work w, int which, int qsel) {
+  constexpr int X = M::X, V = M::V, Z = M::Z;
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x;
+  if (wid >= sy.B * sy.K * sy.NOBS) return;
+  const int m = wid % sy.NOBS;
+  const int cbi = sy.order[wid / sy.NOBS];
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (w.nw[c] != 1) return;
+  const BlockDesc bd = sy.blk[b];
+  if (m >= bd.nobs) return;
+  const int sl_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int S = sy.S;
+  const double* q = (qsel ? w.qb : pick(sl.q, sl_ ^ 1)) + (size_t)c * sy.Q;
+  const double* traj = w.trajw + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X + (size_t)m * S * X;
+  const double* PBr = pick(sl.PB, sl_) + ((size_t)c * sy.T * S + bd.step0 + (size_t)m * S) * (X * V);
+  const double* vbase = q + sy.U + sy.V0 + ((size_t)bd.step0 + (size_t)m * S) * V;
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  double Wacc[X * Z], Sacc[X * X], Pf[X * X];
+#pragma unroll
+  for (int i = 0; i < X * Z; ++i) Wacc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) Sacc[i] = 0.0, Pf[i] = (i / X == i % X) ? 1.0 : 0.0;
+  const int ntile = (S + 63) >> 6;
+  struct Raw {
+    double x[X], v[V], jp[X * V];
+    bool valid;
+  };
+  auto fetch = [&](int t, Raw& r) {
+    const int off = (t << 6) + (63 - lane);  // later steps in lower lanes (DPP prefix scans)
+    r.valid = t >= 0 && off < S;
+    if (r.valid) {
+#pragma unroll
+      for (int a = 0; a < X; ++a) r.x[a] = ld_stream(traj + (size_t)off * X + a);
+#pragma unroll
+      for (int a = 0; a < V; ++a) r.v[a] = vbase[(size_t)off * V + a];
+#pragma unroll
+      for (int k = 0; k < X * V; ++k) r.jp[k] = ld_stream(PBr + (size_t)off * (X * V) + k);
+    } else {
+#pragma unroll
+      for (int a = 0; a < X; ++a) r.x[a] = 0.0;
+#pragma unroll
+      for (int a = 0; a < V; ++a) r.v[a] = 0.0;
+#pragma unroll
+      for (int k = 0; k < X * V; ++k) r.jp[k] = 0.0;
+    }
+  };
+  Raw r0, r1;
+  fetch(ntile - 1, r0);
+  for (int t = ntile - 1; t >= 0; --t) {
+    fetch(t - 1, r1);
+    double A[X * X], Bm[X * V], Zf[X * Z];
+    if (r0.valid) {
+      M::jac(cc.k, r0.x, r0.v, A, Bm, Zf);
+    } else {
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+      for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+    }
+    double Inc[X * X], E[X * X], I0[X * X], PE[X * X], T[X * V];
+    dpp_prefix_products<X>(A, Inc, E);
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) I0[i] = bcast_lane63(Inc[i]);
+    matmul_xx<X>(Pf, E, PE);
+#pragma unroll
+    for (int a = 0; a < X; ++a)
+#pragma unroll
+      for (int d = 0; d < V; ++d) {
+        double tt2 = 0.0;
+#pragma unroll
+        for (int e = 0; e < X; ++e) tt2 += PE[a * X + e] * Bm[e * V + d];
+        T[a * V + d] = tt2;
+      }
+#pragma unroll
+    for (int a = 0; a < X; ++a)
+#pragma unroll
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt2 = Wacc[a * Z + mz];
+#pragma unroll
+        for (int e = 0; e < X; ++e) tt2 += PE[a * X + e] * Zf[e * Z + mz];
+        Wacc[a * Z + mz] = tt2;
+      }
+#pragma unroll
+    for (int a = 0; a < X; ++a)
+#pragma unroll
+      for (int a2 = 0; a2 < X; ++a2) {
+        double tt2 = Sacc[a * X + a2];
+#pragma unroll
+        for (int d = 0; d < V; ++d) tt2 += T[a * V + d] * r0.jp[a2 * V + d];
+        Sacc[a * X + a2] = tt2;
+      }
+    {
+      double Pn[X * X];
+      matmul_xx<X>(Pf, I0, Pn);
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Pf[i] = Pn[i];
+    }
+    r0 = r1;
+  }
+  double* out = w.ivl + (cb * sy.NOBS + m) * CHMC_IVL_N(X, Z);
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) {
+    double v = Sacc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) out[i] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < X * Z; ++i) {
+    double v = Wacc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) out[X * X + i] = v;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) out[X * X + X * Z + i] = Pf[i];
+  }
+}
+
+template <class M, int RM>
+__global__ void __launch_bounds__(64) k_newton_comb(Sys sy, Slots sl, Work w, int which, int qsel) {
+  constexpr int X = M::X, Z = M::Z, U = M::U, V0 = M::V0;
+  constexpr int NI = CHMC_IVL_N(X, Z);
+  __shared__ double LamF[RM * X], LamN[RM * X], Dl[RM * RM], zl[RM * Z], Ys[RM * X], Iv[NI];
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x;
+  if (wid >= sy.B * sy.K) return;
+  const int cbi = sy.order[wid];
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (w.nw[c] != 1) return;
+  const BlockDesc bd = sy.blk[b];
+  const int sl_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int S = sy.S, NV = sy.NV;
+  const double* q = (qsel ? w.qb : pick(sl.q, sl_ ^ 1)) + (size_t)c * sy.Q;
+  const double* traj = w.trajw + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* Jr = pick(sl.Jv, sl_) + (size_t)c * RM * NV;
+  const double* LFr = pick(sl.LF, sl_) + cb * sy.NOBS * RM * X;
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int e = lane; e < RM * X; e += 64) LamF[e] = 0.0;
+  for (int e = lane; e < RM * RM; e += 64) Dl[e] = 0.0;
+  for (int e = lane; e < RM * Z; e += 64) zl[e] = 0.0;
+  lds_sync();
+  for (int m = bd.nobs - 1; m >= 0; --m) {
+    // rows that start at the end of observation interval m
+    if (m < bd.ny) {
+      double g[X], gl = 0.0;
+      M::obs_grad(traj + (size_t)(m + 1) * S * X, g);
+#pragma unroll
+      for (int a = 0; a < X; ++a) gl = lane == a ? g[a] : gl;
+      if (lane < X) LamF[m * X + lane] = gl;
+    }
+    if (m == bd.nobs - 1 && !bd.last) {
+      if (lane < X) LamF[(bd.ny + lane) * X + lane] = 1.0;
+    }
+    const double* iv = w.ivl + (cb * sy.NOBS + m) * NI;
+    for (int e = lane; e < NI; e += 64) Iv[e] = iv[e];
+    lds_sync();
+    // Ys[jj][a] = sum_a2 Ss[a][a2] LFprev[m][jj][a2]
+    for (int e = lane; e < RM * X; e += 64) {
+      const int jj = e / X, a = e - jj * X;
+      const double* lf = LFr + ((size_t)m * RM + jj) * X;
+      double tt = 0.0;
+#pragma unroll
+      for (int a2 = 0; a2 < X; ++a2) tt += Iv[a * X + a2] * lf[a2];
+      Ys[e] = tt;
+    }
+    lds_sync();
+    for (int e = lane; e < RM * RM; e += 64) {
+      const int i = e / RM, jj = e - i * RM;
+      double tt = Dl[e];
+#pragma unroll
+      for (int a = 0; a < X; ++a) tt += LamF[i * X + a] * Ys[jj * X + a];
+      Dl[e] = tt;
+    }
+    for (int e = lane; e < RM * Z; e += 64) {
+      const int i = e / Z, mz = e - i * Z;
+      double tt = zl[e];
+#pragma unroll
+      for (int a = 0; a < X; ++a) tt += LamF[i * X + a] * Iv[X * X + a * Z + mz];
+      zl[e] = tt;
+    }
+    // the rows at the interval's start: LamF Pt[m]
+    for (int e = lane; e < RM * X; e += 64) {
+      const int i = e / X, d = e - i * X;
+      double tt = 0.0;
+#pragma unroll
+      for (int a = 0; a < X; ++a) tt += LamF[i * X + a] * Iv[X * X + X * Z + a * X + d];
+      LamN[e] = tt;
+    }
+    lds_sync();
+    for (int e = lane; e < RM * X; e += 64) LamF[e] = LamN[e];
+    lds_sync();
+  }
+  // x_0 = generate_x_0(z, v_0): the v_0 columns and the z-dependence of the first block
+  if (bd.first) {
+    double dz[X * Z], dv0[X * V0];
+    M::gx0_jac(dz, dv0);
+    for (int e = lane; e < RM * RM; e += 64) {
+      const int i = e / RM, jj = e - i * RM;
+      double tt = Dl[e];
+      for (int d = 0; d < V0; ++d) {
+        double j0 = 0.0;
+        for (int a = 0; a < X; ++a) j0 += LamF[i * X + a] * dv0[a * V0 + d];
+        tt += j0 * Jr[(size_t)jj * NV + d];
+      }
+      Dl[e] = tt;
+    }
+    for (int e = lane; e < RM * Z; e += 64) {
+      const int i = e / Z, mz = e - i * Z;
+      double tt = zl[e];
+      for (int a = 0; a < X; ++a) {
+        double dzs = 0.0;
+#pragma unroll
+        for (int ee = 0; ee < X * Z; ++ee) dzs = ee == a * Z + mz ? dz[ee] : dzs;
+        tt += LamF[i * X + a] * dzs;
+      }
+      zl[e] = tt;
+    }
+  }
+  lds_sync();
+  for (int e = lane; e < RM * RM; e += 64) {  // noise term on the observation rows, identity padding
+    const int i = e / RM, jj = e - i * RM;
+    double v = Dl[e];
+    if (i == jj) {
+      const double sg_ = sy.noisy ? sigma_at(sy, q) : 0.0;
+      if (sy.noisy && i < bd.ny) v += sg_ * sigma_at(sy, pick(sl.q, sl_) + (size_t)c * sy.Q);  // dc_dn_l * dc_dn_r (:772-791)
+      if (i >= bd.nrows) v = 1.0;
+    }
+    w.Dw[cb * RM * RM + e] = v;
+  }
+  double G[Z * Z];
+  M::gz_jac(q, G);
+  for (int e = lane; e < RM * U; e += 64) {  // dc/du rows of the iterate through generate_z'(u)
+    const int i = e / U, d = e - i * U;
+    double tt = 0.0;
+    if (d < Z) {
+      for (int mz = 0; mz < Z; ++mz) {
+        double gs = 0.0;
+#pragma unroll
+        for (int ee = 0; ee < Z * Z; ++ee) gs = ee == mz * Z + d ? G[ee] : gs;
+        tt += zl[i * Z + mz] * gs;
+      }
+    } else {
+      tt = i < bd.ny ? sigma_at(sy, q) * q[sy.U + sy.NV + bd.obs0 + i] : 0.0;
+    }
+    w.JuL[cb * RM * U + e] = tt;
+  }
+}
+
 // Reverse sweep for 16-row blocks with the row-indexed state in LDS (see k_gld_bwd_wave_ldsrows: at 16 rows the fully
 // unrolled k_rev_wave<.., GRAM = false> keeps 48 + 64 + 48 doubles of rows per lane and spills).  The row loop is rolled;
 // the carried adjoint rows (wave-uniform) and the per-lane dc/dz partial sums (one LDS column per lane, conflict-free)
@@ -1038,6 +1312,15 @@ __global__ void __launch_bounds__(64) k_rev_wave_ldsrows(Sys sy, Slots sl, Work 
   for (int i = lane; i < RM * X; i += 64) LamS[i] = 0.0;
   for (int i = 0; i < RM * Z; ++i) zaccS[i * 64 + lane] = 0.0;
   lds_sync();
+  double* PBo = nullptr;  // compact rows of the evaluated state (MODE 0): Slots::PB / Slots::LF
+  double* LFo = nullptr;
+  if (MODE == 0 && pick(sl.PB, sl_)) {
+    PBo = pick(sl.PB, sl_) + (size_t)c * sy.T * sy.S * (X * V);
+    LFo = pick(sl.LF, sl_) + cb * sy.NOBS * RM * X;
+  }
+  double Pf[X * X];
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) Pf[i] = (i / X == i % X) ? 1.0 : 0.0;
   const int ntile = (S + 63) >> 6;
   struct Raw {
     double x[X], v[V];
@@ -1071,6 +1354,11 @@ __global__ void __launch_bounds__(64) k_rev_wave_ldsrows(Sys sy, Slots sl, Work 
         if (lane < X) LamS[(bd.ny + lane) * X + lane] = 1.0;
       }
       lds_sync();
+      if (MODE == 0 && PBo) {  // compact rows (Slots::PB / LF): the frame of interval j, products restart
+        for (int e = lane; e < RM * X; e += 64) LFo[(size_t)j * RM * X + e] = LamS[e];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Pf[i] = (i / X == i % X) ? 1.0 : 0.0;
+      }
     }
     double A[X * X], Bm[X * V], Zf[X * Z];
     if (r0.valid) {
@@ -1092,6 +1380,26 @@ __global__ void __launch_bounds__(64) k_rev_wave_ldsrows(Sys sy, Slots sl, Work 
       I0[i] = bcast_lane63(Inc[i]);
     }
     const size_t col = colb + (size_t)r0.s * V;
+    if (MODE == 0 && PBo) {  // PB[s] = Pf E_s B_s: the row-independent factor of the step's rows
+      double PE[X * X];
+      matmul_xx<X>(Pf, E, PE);
+      if (r0.valid) {
+        double* dst = PBo + (size_t)(bd.step0 + r0.s) * (X * V);
+#pragma unroll
+        for (int a = 0; a < X; ++a)
+#pragma unroll
+          for (int d = 0; d < V; ++d) {
+            double tt2 = 0.0;
+#pragma unroll
+            for (int e = 0; e < X; ++e) tt2 += PE[a * X + e] * Bm[e * V + d];
+            dst[a * V + d] = tt2;
+          }
+      }
+      double Pn[X * X];
+      matmul_xx<X>(Pf, I0, Pn);
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Pf[i] = Pn[i];
+    }
 #pragma unroll 1
     for (int i = 0; i < RM; ++i) {  // rolled: everything indexed by i lives in LDS or global memory
       double Ls[X];
@@ -2882,7 +3190,15 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
   // (ii) makes the sweeps exact after at most 64 of them, but a block that is not settled after a dozen belongs to a
   // chain whose retraction is diverging (healthy blocks settle in 2-9 sweeps): it is handed to the sequential
   // recursion, which costs the same 0.9 ms as the remaining sweeps would
-  constexpr int X = M::X, V = M::V, MAXS = 12;
+  constexpr int X = M::X, V = M::V;
+  // Inside a Newton loop with one block per chain an unsettled chain is parked for the side stream (below) and the whole
+  // round waits for the slowest wavefront of this launch: 99.8 % of the scans settle within 6 sweeps (tools/
+  // par_scan_stats.py).  (Stopping the loop's launches at 6 sweeps was measured slower, 19.6 -> 21.0 ms per step: every
+  // parked chain sits out CHMC_REJOIN rounds, which lengthens the loop by more than the shorter launches save.)
+#ifndef CHMC_PAR_MAXS_LOOP
+#define CHMC_PAR_MAXS_LOOP 12
+#endif
+  const int MAXS = (use_nw && sy.K == 1) ? CHMC_PAR_MAXS_LOOP : 12;
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x;
   if (wid >= sy.B * sy.K) return;
@@ -2890,12 +3206,14 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
   const int c = cbi / sy.K, b = cbi - c * sy.K;
   if (use_nw ? w.nw[c] == 0 : !w.ok[c]) return;
   if (use_nw && w.nw[c] != 1) {
-    // (K = 1) the scan of this chain's current iterate was handed to the side stream two rounds ago, and the host has
+    // (K = 1) the scan of this chain's current iterate was handed to the side stream CHMC_REJOIN rounds ago, and the host has
     // made this launch wait for that piece of side-stream work: the chain re-joins the loop with its result (its iterate
     // has not changed meanwhile).  Flags of later rounds may be changing under our eyes and are not looked at.
-    if (lane == 0 && w.nw[c] == 32 + ((round + 2) & 3)) w.nw[c] = 1;
+    if (lane == 0 && w.nw[c] == 32 + ((round + 4 - CHMC_REJOIN) & 3)) w.nw[c] = 1;
     return;
   }
+  // (Sending every later iterate of a chain that was parked once straight to the side stream was measured much slower,
+  // 19.6 -> 31 ms per step: most such chains settle again, and a parked iterate costs 0.9 ms plus CHMC_REJOIN rounds.)
   const BlockDesc bd = sy.blk[b];
   const int s_ = sl.cur[c] ^ which;
   const int S = sy.S, L = bd.nsteps;
