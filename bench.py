@@ -208,7 +208,12 @@ def class_model(ctx, wl, model, newton):
     # structurally non-zero entries of the stored dc/dv rows (the reference's dense blocks hold `nnz`; the row-slot layout
     # lets the kernels skip an observation row after its own interval) + the observation-noise columns
     nnz_live = live * ctx.V + (ctx.T if ctx.noisy else 0)
-    hbm = {"update": 8.0 * (nnz_live + 2 * Q), "jacob_vec": 8.0 * (nnz_live + Q), "elementwise": 8.0 * 3 * Q}
+    # the Newton-loop and projection passes read the COMPACT rows: X V doubles per step (Slots::PB) + the frames
+    n_pb = n_s * ctx.X * ctx.V + (ctx.T if ctx.noisy else 0)
+    n_rows = min(nnz_live, n_pb)
+    hbm = {"update": 8.0 * (n_rows + 2 * Q), "jacob_vec": 8.0 * (n_rows + 2 * Q), "elementwise": 8.0 * 3 * Q,
+           # traj + v + compact rows read per step; nothing per-step is written
+           "newton_blk": 8.0 * (n_s * ctx.X + Q + n_rows)}
     cm = _class_model_operator(nnz, Q, jac, gram_ns, gram_sym, f, n_s)
     for k, v in hbm.items():
         cm[k]["hbm_bytes"] = v  # what the fused kernel has to move across HBM (<= the operator-level figure)
@@ -388,15 +393,22 @@ def main():
         alg_bytes = mdl["bytes"] * chains_per_launch
         alg_flops = mdl["flops"] * chains_per_launch
         sec = avg_ms * 1e-3
-        if bound == "hbm":
+        if name == "constr":
+            # the forward scans are sequential recursions, one lane per (chain, block): what binds them is the latency of
+            # the dependent fp64 instructions of one step (tools/ubench/fwd_latency.hip: 36 ns per FitzHugh-Nagumo step)
+            steps = max(b["nsteps"] for b in ctx.blocks[ctx.partition])
+            achieved, unit = steps / sec / 1e6, "Msteps/s per lane"
+            peak = 1e3 / 36.0 if model == "fhn" else None
+            bound = "latency"
+        elif bound == "hbm":
             # HBM-bound classes are priced on the bytes the kernel has to move given the row-slot layout (structural
             # zeros skipped, read-modify-write fused); the operator-level figure stays in `algorithmic_bytes_GBs`
             achieved, peak, unit = mdl.get("hbm_bytes", mdl["bytes"]) * chains_per_launch / sec / 1e9, HBM_PEAK_GBS, "GB/s"
         else:  # fp64_valu: algorithmic fp64 flops of the launch against the fp64 vector peak
             achieved, peak, unit = alg_flops / sec / 1e12, FP64_VALU_PEAK_TFLOPS, "TFLOP/s"
         roofline = {
-            "bound": bound if bound != "latency" else "fp64_valu", "kernel": name, "achieved": achieved, "peak": peak,
-            "unit": unit, "frac": achieved / peak, "traffic": traffic,
+            "bound": bound if (bound != "latency" or name == "constr") else "fp64_valu", "kernel": name,
+            "achieved": achieved, "peak": peak, "unit": unit, "frac": (achieved / peak) if peak else None, "traffic": traffic,
             "hbm_traffic_frac": (traffic / sec / 1e9 / HBM_PEAK_GBS) if traffic else None, "traffic_source": traffic_note,
             "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
             "algorithmic_bytes_GBs": alg_bytes / sec / 1e9,
@@ -413,6 +425,11 @@ def main():
                     "stream; `algorithmic_bytes_GBs` is the operator-level rate of SURVEY.md 8d (dense blocks, unfused "
                     "operators), a throughput figure that may exceed the HBM peak",
         }
+        if name == "constr":
+            roofline["note"] = ("achieved = sequential steps of the longest block / average launch time by HIP events on the "
+                                "library's stream; peak = 1 / (36 ns per step), the dependent-instruction latency floor of one "
+                                "FitzHugh-Nagumo step at one wavefront per SIMD (tools/ubench/fwd_latency.hip); a launch keeps "
+                                "B x K lanes = 80 wavefronts busy, so neither HBM nor the vector pipes bound it")
         # the whole step attributed: every class with its time, binding resource and fraction of that resource's peak
         table = {}
         for i, k in enumerate(_lib.KERNEL_CLASSES):

@@ -18,7 +18,9 @@ SO = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "
                   "libchmc_hip.so")
 
 CLASS_OF = [  # substring of the kernel name -> profiling class of include/chmc.h (first match wins)
-    ("k_newton_lean", "newton_blk"), ("k_newton_factor_wave", "sym_blk"), ("k_gram_rows", "newton_blk"),
+    ("k_newton_lean", "newton_blk"), ("k_newton_ivl", "newton_blk"), ("k_newton_comb", "newton_blk"),
+    ("k_newton_factor_wave", "sym_blk"), ("k_gram_rows", "newton_blk"), ("KUpdatePB", "update"), ("KMuF", "solve_chain"),
+    ("k_jw_pb", "jacob_vec"), ("KRowsFromPB", "state_blk"),
     ("k_rev_wave_ldsrows<chmc::SirModel, 16, 1", "newton_blk"), ("k_rev_wave_ldsrows<chmc::SirVsModel, 16, 1", "newton_blk"),
     ("k_rev_wave_ldsrows", "state_blk"),
     ("k_rev_wave<chmc::FhnModel, 7, 1", "newton_blk"), ("k_rev_wave<chmc::FhnModel, 7, 0", "state_blk"),
