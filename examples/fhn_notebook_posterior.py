@@ -104,15 +104,23 @@ def run(num_chains=64, n_iter=700, n_warm=200, n_step=24, out_dir=None, seed=202
     tr = {k: np.load(f) for k, f in res["trace_files"].items()}
     moved = np.diff(tr["σ"][:, n_warm:], axis=1) != 0
     moving = moved.mean(1) >= 0.1
-    # ... and a chain that is released from such a start only during the main phase (moving in less than half of the
-    # transitions of some 50-transition window, then travelling to the bulk) is still in its transient: left out as well
-    nwin = max(moved.shape[1] // 50, 1)
-    moving &= np.array([w.mean(1) for w in np.array_split(moved, nwin, axis=1)]).min(0) >= 0.5
+    # ... and a chain that is released from such a start only during the main phase and then travels to the bulk is still
+    # in its transient.  Burn-in check per chain (Geweke-style): the mean of a parameter over the first fifth of the main
+    # phase against its mean over the second half, in units of the pooled within-chain standard deviation of the moving
+    # chains' second halves; more than 4 of those for any of the four parameters -> left out as well (healthy chains: < 1).
+    n_main = tr["σ"].shape[1] - n_warm
+    drift = np.zeros(num_chains)
+    for k in ("σ", "ϵ", "γ", "β"):
+        v = tr[k][:, n_warm:]
+        late = v[:, n_main // 2:]
+        sd = np.sqrt(np.mean(late[moving].var(1))) if moving.any() else 1.0
+        drift = np.maximum(drift, np.abs(v[:, :max(n_main // 5, 1)].mean(1) - late.mean(1)) / max(sd, 1e-300))
+    moving &= drift <= 4.0
     sm = summarize({k: v[moving][:, n_warm:] for k, v in tr.items()})
     if verbose and not moving.all():
         # diagnosis of the chains left out: where their parameters sit and how their transitions ended
         sm_all = summarize({k: v[:, n_warm:] for k, v in tr.items()})
-        print("chains left out of the summary (moved in < 10 % of the main transitions, or in < 50 % of some window of 50):")
+        print("chains left out of the summary (moved in < 10 % of the main transitions, or still drifting: first fifth vs second half > 4 sd):")
         oc = res.get("chain_outcomes")
         for c in np.flatnonzero(~moving):
             line = f"  chain {c:3d}: sigma {tr['σ'][c, -1]:.3f} eps {tr['ϵ'][c, -1]:.4f} gamma {tr['γ'][c, -1]:.3f} beta {tr['β'][c, -1]:.3f}"

@@ -4,9 +4,9 @@ is re-run on the GPU (same data from the same legacy seed, same model, priors, d
 tolerances; a static-trajectory sampler instead of Mici's dynamic one, 64 chains instead of 2) and the posterior means
 must agree within Monte-Carlo error, the posterior standard deviations within 15 %.  Selection step (not in the
 reference, whose two chains were simply two usable prior draws): candidate starts are screened by a short pilot run and
-chains that move in fewer than 10 % of their main transitions (unusable starts), or in fewer than half of the transitions
-of some 50-transition window of the main phase (released late: still in their transient), are left out of the summary and
-counted."""
+chains that move in fewer than 10 % of their main transitions (unusable starts), or whose parameter means over the first
+fifth and the second half of the main phase differ by more than 4 within-chain standard deviations (released late: still
+in their transient), are left out of the summary and counted."""
 import os
 import sys
 import numpy as np

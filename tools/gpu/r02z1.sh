@@ -21,7 +21,7 @@ for f in sorted(glob.glob('gpurun_out/r02z/bench_*.json')):
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
         r = d['roofline']
-        print(f.split('/')[-1], round(d['value']), round(d['ms_per_step'], 3), r['kernel'], r['bound'], round(r['frac'], 3),
+        print(f.split('/')[-1], round(d['value']), round(d['ms_per_step'], 3), r['kernel'], r['bound'], r['frac'],
               round(r['avg_launch_ms'], 4), d.get('cpu_baseline'))
     except Exception as e:
         print(f, 'ERR', e)
