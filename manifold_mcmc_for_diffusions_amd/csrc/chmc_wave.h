@@ -1982,7 +1982,9 @@ __global__ void __launch_bounds__(256) k_jw_pb(Sys sy, Slots sl, Work w, int whi
 // PBJ (both sweeps): the stored rows are read in their compact form (Slots::PB / LF).  The weights w_i = sum_jj
 // (G^-1)_i,jj dc_jj/dv_s are then  MLF[m][i] . PB[s]  with the per-interval RM x X matrix MLF[m] = (G^-1)_bb LF[m]
 // (wave-uniform, formed once per interval): X V doubles per step instead of RM V, RM X V multiply-adds instead of RM RM V.
-template <class M, int RM, bool PBJ = false>
+// QX (with PBJ): instead of the tangents the sweep stores Qx_s = sum_i LF[m][i]^T xd_i(s)^T (X x X per step), which is all
+// the row-free backward sweep k_gld_bwd_lean needs of them.
+template <class M, int RM, bool PBJ = false, bool QX = false>
 __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, int which) {
   constexpr int X = M::X, V = M::V, Z = M::Z, V0 = M::V0;
   constexpr int URM = 64;  // (the forward sweep is correct fully unrolled at 16 rows as well; the backward sweep is not, see there)
@@ -2016,7 +2018,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   ChainConsts<M> cc;
   cc.init(q, sy.dl);
-  double mlf[PBJ ? RM * X : 1];
+  double mlf[PBJ ? RM * X : 1], lf[QX ? RM * X : 1];
   double xdc[RM * X];  // tangents at the start of the current tile (wave-uniform)
 #pragma unroll URM
   for (int i = 0; i < RM * X; ++i) xdc[i] = 0.0;
@@ -2050,6 +2052,10 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int e2 = 0; e2 < RM * X; ++e2) mlf[e2] = MLFs[e2];
+      if constexpr (QX) {
+#pragma unroll
+        for (int e2 = 0; e2 < RM * X; ++e2) lf[e2] = LFr[(size_t)j * RM * X + e2];
+      }
     }
     for (int t = 0; t < ntile; ++t) {
       const int off = (t << 6) + lane;
@@ -2161,6 +2167,19 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
             for (int d = 0; d < X; ++d) tt += Pex[a * X + d] * xdc[i * X + d];
             xs[i * X + a] = tt;
           }
+        if constexpr (QX) {
+          if (valid) {
+#pragma unroll
+            for (int a1 = 0; a1 < X; ++a1)
+#pragma unroll
+              for (int a2 = 0; a2 < X; ++a2) {
+                double tt = 0.0;
+#pragma unroll
+                for (int i = 0; i < RM; ++i) tt += (i >= j && i < bd.nrows) ? lf[i * X + a1] * xs[i * X + a2] : 0.0;
+                st_async(Xd + (size_t)(a1 * X + a2) * TS + s, tt);
+              }
+          }
+        } else
         if (valid) {  // the tangent of row i is only needed up to that row's own observation time
 #pragma unroll URM
           for (int i = 0; i < RM; ++i)
@@ -2474,6 +2493,261 @@ __global__ void __launch_bounds__(PBJ && CHMC_GLD_BWD_WAVES > 1 ? 64 : 256, PBJ 
     for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
   }
 }
+
+
+// The backward grad-log-det sweep without a row index in its hot loop (compact rows, blocks of at most 8 rows).  With the
+// frames the Hessian-contraction source of a step is
+//     Sm[a][.] = sum_i Ls_i[a] dir_i[.] = sum_a' PE_s[a'][a] Q_s[a'][.],    Q_s[a'][.] = sum_i LF[m][i][a'] dir_i(s)[.],
+// and Q_s splits into   Qx_s = sum_i LF_i^T xd_i(s)^T  (X x X per step: formed and stored by the FORWARD sweep, which holds
+// the tangents, instead of the tangents themselves -- X X doubles per step instead of up to RM X),
+// Qv_s = C[m] PB[s] with C[m] = LF[m]^T MLF[m] (X x X per interval),  Qz = LF[m]^T zd (X x Z per interval).
+// No adjoint rows are carried (LF[m] holds them), no per-row loads or loops: the kernel fits two wavefronts per SIMD.
+#ifndef CHMC_GLD_LEAN_WAVES
+#define CHMC_GLD_LEAN_WAVES 2
+#endif
+template <class M, int RM>
+__global__ void __launch_bounds__(64, CHMC_GLD_LEAN_WAVES) k_gld_bwd_lean(Sys sy, Slots sl, Work w, int which) {
+  constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0, NXI = M::NXI;
+  static_assert(RM <= 8, "blocks of at most 8 rows");
+  __shared__ double Mb[RM * RM], zd[RM * Z], LFs[RM * X], MLFs[RM * X], CQ[X * X + X * Z];
+  const int lane = threadIdx.x & 63;
+  const int wid = blockIdx.x;
+  if (wid >= sy.B * sy.K) return;
+  const int cbi = sy.order[wid];  // work order: longest blocks first
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (!w.ok[c]) return;
+  const BlockDesc bd = sy.blk[b];
+  const int s_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int S = sy.S;
+  const size_t TS = (size_t)sy.T * S;
+  const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
+  const double* Xq = w.Xd + (size_t)c * RM * X * TS + bd.step0;  // Qx, component-major: [X X][T S]
+  double* gv = pick(sl.grad, s_) + (size_t)c * sy.Q + sy.U;
+  const double* PBr = pick(sl.PB, s_) + ((size_t)c * TS + bd.step0) * (X * V);
+  const double* LFr = pick(sl.LF, s_) + cb * sy.NOBS * RM * X;
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int i = lane; i < RM * RM; i += 64) Mb[i] = w.gMb[cb * RM * RM + i];
+  for (int i = lane; i < RM * Z; i += 64) zd[i] = w.gzd[cb * RM * Z + i];
+  lds_sync();
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  double xb[X], zbt[Z], Pf[X * X], Cm[X * X], Qz[X * Z];
+#pragma unroll
+  for (int i = 0; i < X; ++i) xb[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < Z; ++i) zbt[i] = 0.0;
+  const int ntile = (S + 63) >> 6;
+  for (int j = bd.nobs - 1; j >= 0; --j) {
+    if (j < bd.ny) {
+      double hv[X], xt[X];
+      for (int a = 0; a < X; ++a) xt[a] = w.gxdt[(cb * RM + j) * X + a];
+      M::obs_hess_vec(traj + (size_t)(j + 1) * S * X, xt, hv);
+#pragma unroll
+      for (int a = 0; a < X; ++a) xb[a] += hv[a];
+    }
+    // per-interval matrices: MLF = (G^-1)_bb LF[j], C = LF^T MLF, Qz = LF^T zd
+    lds_sync();
+    for (int e = lane; e < RM * X; e += 64) LFs[e] = LFr[(size_t)j * RM * X + e];
+    lds_sync();
+    for (int e = lane; e < RM * X; e += 64) {
+      const int i = e / X, a = e - i * X;
+      double t2 = 0.0;
+      for (int jj = 0; jj < RM; ++jj) t2 += Mb[i * RM + jj] * LFs[jj * X + a];
+      MLFs[e] = t2;
+    }
+    lds_sync();
+    for (int e = lane; e < X * X + X * Z; e += 64) {
+      double t2 = 0.0;
+      if (e < X * X) {
+        const int a1 = e / X, a2 = e - a1 * X;
+        for (int i = 0; i < RM; ++i) t2 += LFs[i * X + a1] * MLFs[i * X + a2];
+      } else {
+        const int a1 = (e - X * X) / Z, mz = (e - X * X) - a1 * Z;
+        for (int i = 0; i < RM; ++i) t2 += LFs[i * X + a1] * zd[i * Z + mz];
+      }
+      CQ[e] = t2;
+    }
+    lds_sync();
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) Cm[i] = CQ[i], Pf[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < X * Z; ++i) Qz[i] = CQ[X * X + i];
+    for (int t = ntile - 1; t >= 0; --t) {
+      const int off = (t << 6) + (63 - lane);  // LATER steps in LOWER lanes: the suffix scans become DPP prefix scans
+      const bool valid = off < S;
+      const int s = j * S + off;
+      const size_t col = colb + (size_t)s * V;
+      double A[X * X], Bm[X * V], Zf[X * Z], x[X], vv[V], pb[X * V], qx[X * X];
+      if (valid) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) x[a] = ld_stream(traj + (size_t)s * X + a);
+#pragma unroll
+        for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
+#pragma unroll
+        for (int k = 0; k < X * V; ++k) pb[k] = ld_stream(PBr + (size_t)s * (X * V) + k);
+#pragma unroll
+        for (int k = 0; k < X * X; ++k) qx[k] = ld_stream(Xq + (size_t)k * TS + s);
+        M::jac(cc.k, x, vv, A, Bm, Zf);
+      } else {
+#pragma unroll
+        for (int a = 0; a < X; ++a) x[a] = 0.0;
+#pragma unroll
+        for (int a = 0; a < V; ++a) vv[a] = 0.0;
+#pragma unroll
+        for (int k = 0; k < X * V; ++k) pb[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < X * X; ++k) qx[k] = 0.0;
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+      }
+      double Inc[X * X], E[X * X], PE[X * X];
+      dpp_prefix_products<X>(A, Inc, E);
+      matmul_xx<X>(Pf, E, PE);
+      // Hessian contraction source of this step: Sm = PE^T [ Qx | C PB | Qz ]
+      double H[NXI];
+      {
+        double Q[X * NXI], Sm[X * NXI];
+#pragma unroll
+        for (int a1 = 0; a1 < X; ++a1) {
+#pragma unroll
+          for (int a2 = 0; a2 < X; ++a2) Q[a1 * NXI + a2] = qx[a1 * X + a2];
+#pragma unroll
+          for (int d = 0; d < V; ++d) {
+            double tt = 0.0;
+#pragma unroll
+            for (int a2 = 0; a2 < X; ++a2) tt += Cm[a1 * X + a2] * pb[a2 * V + d];
+            Q[a1 * NXI + X + d] = tt;
+          }
+#pragma unroll
+          for (int mz = 0; mz < Z; ++mz) Q[a1 * NXI + X + V + mz] = Qz[a1 * Z + mz];
+        }
+#pragma unroll
+        for (int a = 0; a < X; ++a)
+#pragma unroll
+          for (int m2 = 0; m2 < NXI; ++m2) {
+            double tt = 0.0;
+#pragma unroll
+            for (int a1 = 0; a1 < X; ++a1) tt += PE[a1 * X + a] * Q[a1 * NXI + m2];
+            Sm[a * NXI + m2] = tt;
+          }
+        M::hess(cc.k, x, vv, Sm, H);
+        if (!valid) {
+#pragma unroll
+          for (int i = 0; i < NXI; ++i) H[i] = 0.0;
+        }
+      }
+      // joint suffix scan for x-bar: x-bar^(l) = x-bar^(l+1) A_l + Hx_l
+      double I2[X * X], gi[X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) I2[i] = A[i];
+#pragma unroll
+      for (int a = 0; a < X; ++a) gi[a] = H[a];
+      dpp_rowaffine_prefix<X>(I2, gi);
+      double xbs[X];  // x-bar at the state after this lane's step
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        double tt = dpp_mov<0x138, 0xf, 0xf>(gi[d], 0.0);  // wave_shr:1: the sources of the later steps
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += xb[a] * E[a * X + d];
+        xbs[d] = tt;
+      }
+      if (valid) {
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          double tt = H[X + d];
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt += Bm[a * V + d] * xbs[a];
+          gv[col + d] = tt;
+        }
+      }
+#pragma unroll
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt = H[X + V + mz];
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += Zf[a * Z + mz] * xbs[a];
+        zbt[mz] += tt;
+      }
+      // carries
+      double I0[X * X], g0[X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) I0[i] = bcast_lane63(I2[i]);
+#pragma unroll
+      for (int a = 0; a < X; ++a) g0[a] = bcast_lane63(gi[a]);
+      {
+        double nb[X];
+#pragma unroll
+        for (int d = 0; d < X; ++d) {
+          double tt = g0[d];
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt += xb[a] * I0[a * X + d];
+          nb[d] = tt;
+        }
+#pragma unroll
+        for (int d = 0; d < X; ++d) xb[d] = nb[d];
+      }
+      {
+        double Pn[X * X];
+        matmul_xx<X>(Pf, I0, Pn);
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Pf[i] = Pn[i];
+      }
+    }
+  }
+  if (bd.first && lane == 0) {
+    double dz[X * Z], dv0[X * V0];
+    M::gx0_jac(dz, dv0);
+    for (int d = 0; d < V0; ++d) {
+      double tt = 0.0;
+      for (int a = 0; a < X; ++a) tt += dv0[a * V0 + d] * xb[a];
+      gv[d] = tt;
+    }
+    for (int mz = 0; mz < Z; ++mz) {
+      double tt = 0.0;
+      for (int a = 0; a < X; ++a) tt += dz[a * Z + mz] * xb[a];
+      zbt[mz] += tt;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < Z; ++i) {
+    double v = zbt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    zbt[i] = v;
+  }
+  if (lane == 0) {
+    double Gz[Z * Z], gu[U];
+    M::gz_jac(q, Gz);
+    for (int d = 0; d < Z; ++d) {
+      double tt = 0.0;
+      for (int mz = 0; mz < Z; ++mz) tt += Gz[mz * Z + d] * zbt[mz];
+      gu[d] = tt;
+    }
+    for (int i = 0; i < RM; ++i) {
+      double o[Z], wu[U], zb[Z];
+      for (int d = 0; d < U; ++d) wu[d] = w.gWu[(cb * RM + i) * U + d];
+      for (int mz = 0; mz < Z; ++mz) zb[mz] = w.zbP[(cb * RM + i) * Z + mz];
+      M::gz_hess(q, wu, zb, o);
+      for (int d = 0; d < Z; ++d) gu[d] += o[d];
+    }
+    if constexpr (M::VS)  // variable observation noise: the sigma-dependent entries of J (see var_sigma_grad_terms)
+      gu[Z] = var_sigma_grad_terms<RM>(sy, bd, q, w.gWu + cb * RM * U, U, w.gMb + cb * RM * RM,
+                                       pick(sl.grad, s_) + (size_t)c * sy.Q);
+    for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
+  }
+}
+
+
 
 // The same backward sweep for 16-row blocks.  With 16 rows the row loops of k_gld_bwd_wave cannot be unrolled (register
 // file) and, rolled, they index per-lane arrays at run time, which puts those arrays into scratch memory (4.0 ms per

@@ -1,5 +1,4 @@
 mkdir -p gpurun_out/r02g
-python -m pytest tests -m gpu -x -q > gpurun_out/r02g/pytest.log 2>&1; tail -8 gpurun_out/r02g/pytest.log
-python bench.py --no-cpu-baseline > gpurun_out/r02g/bench.json 2>/dev/null
-python -c "
-import json;d=json.loads(open('gpurun_out/r02g/bench.json').read().strip().splitlines()[-1]);print(round(d['value']),round(d['ms_per_step'],3), d['roofline']['frac'])"
+python -m pytest tests/test_hip_parity.py tests/test_golden.py -m gpu -x -q -k "not halves" 2>&1 | tail -4
+for G in 1 0; do for i in 1 2; do CHMC_GLD_LEAN=$G python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); t=d['config']['kernel_classes_warmup']; print('gld_lean', $G, round(d['value']), round(d['ms_per_step'],3), 'gld', t['grad_log_det_blk']['ms_per_step'], 'ok', d['config']['step_success_rate'])"; done; done
