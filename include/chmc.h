@@ -163,7 +163,17 @@ int chmc_update_x_obs_seq(chmc_ctx* ctx);
  * re-evaluate the state caches */
 int chmc_switch_partition(chmc_ctx* ctx);
 
-/* ---- per-op entry points, evaluated at the current state ------------------------------------------------ */
+/* ---- per-op entry points, evaluated at the current state ------------------------------------------------
+ * Internally the library keeps the dc/dv rows of a state in a compact factored form (per step a row-independent X x V
+ * matrix, per observation interval the RM x X adjoint frame; DESIGN.md section 4 "Compact rows") and the stepping path
+ * never writes the full rows of blocks with at most 8 rows.  The entry points below that return rows or multiply by them
+ * rebuild the row-slot array first (one extra pass, only when called); results are the same to rounding.
+ *
+ * Environment switches (read when a context is created or at first use; for A/B measurements and debugging only):
+ *   CHMC_COMPACT_ROWS=0   stored-rows passes everywhere          CHMC_STORE_ROWS=1  keep writing the full rows as well
+ *   CHMC_COMPACT16=0      stored-rows Newton sweep for 16-row blocks    CHMC_GLD_COMPACT=0 / CHMC_GLD_LEAN=0  older grad-log-det sweeps
+ *   CHMC_NEWTON_LEAN=0    one-wave-per-SIMD Newton sweep          CHMC_GRAM_MFMA=1   fp64-MFMA Gram kernel (16-row blocks)
+ *   CHMC_PAR_SCAN=0/1     time-parallel forward scan off / forced CHMC_HALVES=2      two overlapped half-batches per step */
 int chmc_constr(chmc_ctx* ctx, double* c);                                  /* :473-519, :1151-1155  [B][C] */
 /* :521-624, :1157-1161.  dc_du [B][C][U]; dc_dv [B][RM][NV] row-slot layout (slot i = row i of the block that
  * owns the column); dc/dn is sigma on observation rows (:601-608). */
