@@ -714,11 +714,15 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
 #endif
 // PBJ: the previous point's rows are read in their compact form (Slots::PB / LF): X V doubles per step instead of RM V,
 // an X x X running sum instead of RM x X, and the frames of the previous point applied once per interval.
-template <class M, int RM, bool PBJ = false>
+// STATE (with PBJ): the same sweep as the STATE EVALUATION of slot `which` (k_rev_wave<MODE 0> at a third of its
+// registers): the Gram block is that of the point itself (X x X running sum of T T^T, own frames), the compact rows PB / LF
+// and the v_0 columns of the rows are written, dc/du rows go to the slot and dc/dz rows to work.zbP.
+template <class M, int RM, bool PBJ = false, bool STATE = false>
 __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVES_PB : CHMC_LEAN_WAVES)
     k_newton_lean(Sys sy, Slots sl, Work w, int which, int qsel) {
   constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0;
-  constexpr int NJP = PBJ ? X * V : RM * V, NY = PBJ ? X * X : RM * X;
+  static_assert(PBJ || !STATE, "the state evaluation works on the compact rows");
+  constexpr int NJP = STATE ? 1 : (PBJ ? X * V : RM * V), NY = PBJ ? X * X : RM * X;
   static_assert(RM <= 8, "blocks of at most 8 rows");
   __shared__ double LamF[RM * X], Dl[RM * RM], zl[RM * Z], Ys[RM * X], Ws[X * Z], Ss[X * X];
   const int lane = threadIdx.x & 63;
@@ -726,16 +730,18 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];  // work order: longest blocks first
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (w.nw[c] != 1) return;
+  if (STATE ? !w.ok[c] : w.nw[c] != 1) return;
   const BlockDesc bd = sy.blk[b];
   const int sl_ = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
   const int S = sy.S, NV = sy.NV;
-  const double* q = (qsel ? w.qb : pick(sl.q, sl_ ^ 1)) + (size_t)c * sy.Q;
-  const double* traj = w.trajw + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* q = (STATE ? pick(sl.q, sl_) : (qsel ? w.qb : pick(sl.q, sl_ ^ 1))) + (size_t)c * sy.Q;
+  const double* traj = (STATE ? pick(sl.traj, sl_) : w.trajw) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
   const double* Jr = pick(sl.Jv, sl_) + (size_t)c * RM * NV;
   const double* PBr = PBJ ? pick(sl.PB, sl_) + ((size_t)c * sy.T * S + bd.step0) * (X * V) : nullptr;
   const double* LFr = PBJ ? pick(sl.LF, sl_) + cb * sy.NOBS * RM * X : nullptr;
+  double* PBo = STATE ? pick(sl.PB, sl_) + ((size_t)c * sy.T * S + bd.step0) * (X * V) : nullptr;
+  double* LFo = STATE ? pick(sl.LF, sl_) + cb * sy.NOBS * RM * X : nullptr;
   ChainConsts<M> cc;
   cc.init(q, sy.dl);
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
@@ -772,7 +778,8 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
         const int jj = lane / X, a = lane - jj * X;
         double tt = 0.0;
         if (jprev < bd.nobs) {
-          const double* lf = LFr + ((size_t)jprev * RM + jj) * X;
+          // (STATE: the point's own frame, still in LamF at this point of the flush)
+          const double* lf = STATE ? LamF + jj * X : LFr + ((size_t)jprev * RM + jj) * X;
 #pragma unroll
           for (int a2 = 0; a2 < X; ++a2) tt += Ss[a * X + a2] * lf[a2];
         }
@@ -835,7 +842,9 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
 #pragma unroll
       for (int a = 0; a < V; ++a) r.v[a] = vbase[(size_t)s * V + a];
       const size_t col = colb + (size_t)s * V;
-      if constexpr (PBJ) {
+      if constexpr (STATE) {
+        r.jp[0] = 0.0;
+      } else if constexpr (PBJ) {
 #pragma unroll
         for (int k = 0; k < X * V; ++k) r.jp[k] = ld_stream(PBr + (size_t)s * (X * V) + k);
       } else
@@ -880,6 +889,9 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
         if (lane < X) LamF[(bd.ny + lane) * X + lane] = 1.0;
       }
       lds_sync();
+      if constexpr (STATE) {  // the frame of interval j (Slots::LF)
+        if (lane < RM * X) LFo[(size_t)j * RM * X + lane] = LamF[lane];
+      }
     }
     double A[X * X], Bm[X * V], Zf[X * Z];
     if (r0.valid) {
@@ -917,7 +929,28 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
         for (int e = 0; e < X; ++e) tt2 += PE[a * X + e] * Zf[e * Z + mz];
         Wacc[a * Z + mz] = tt2;
       }
-    if constexpr (PBJ) {
+    if constexpr (STATE) {
+      if (r0.valid) {  // PB[s] = T_s: the compact form of this step's rows (Slots::PB)
+        const int off0 = (t << 6) + (63 - lane);
+        double* dst = PBo + (size_t)(j * S + off0) * (X * V);
+        if ((X * V) % 2 == 0) {
+#pragma unroll
+          for (int k = 0; k + 1 < X * V; k += 2) st_async2(dst + k, T[k], T[k + 1]);
+        } else {
+#pragma unroll
+          for (int k = 0; k < X * V; ++k) st_async(dst + k, T[k]);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < X; ++a)
+#pragma unroll
+        for (int a2 = 0; a2 < X; ++a2) {
+          double tt2 = Yacc[a * X + a2];
+#pragma unroll
+          for (int d = 0; d < V; ++d) tt2 += T[a * V + d] * T[a2 * V + d];
+          Yacc[a * X + a2] = tt2;
+        }
+    } else if constexpr (PBJ) {
 #pragma unroll
       for (int a = 0; a < X; ++a)
 #pragma unroll
@@ -955,9 +988,10 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
       const int i = lane / RM, jj = lane - i * RM;
       double tt = Dl[lane];
       for (int d = 0; d < V0; ++d) {
-        double j0 = 0.0;
-        for (int a = 0; a < X; ++a) j0 += LamF[i * X + a] * dv0[a * V0 + d];
-        tt += j0 * Jr[(size_t)jj * NV + d];
+        double j0 = 0.0, j1 = 0.0;
+        for (int a = 0; a < X; ++a) j0 += LamF[i * X + a] * dv0[a * V0 + d], j1 += LamF[jj * X + a] * dv0[a * V0 + d];
+        tt += j0 * (STATE ? j1 : Jr[(size_t)jj * NV + d]);
+        if (STATE && jj == 0) pick(sl.Jv, sl_)[(size_t)c * RM * NV + (size_t)i * NV + d] = j0;  // the rows' v_0 columns
       }
       Dl[lane] = tt;
     }
@@ -980,6 +1014,7 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
     if (i == jj) {
       const double sg_ = sy.noisy ? sigma_at(sy, q) : 0.0;
       if (sy.noisy && i < bd.ny) v += sg_ * sigma_at(sy, pick(sl.q, sl_) + (size_t)c * sy.Q);  // dc_dn_l * dc_dn_r (:772-791)
+      // (STATE: q is the slot's own point, so this is sigma^2)
       if (i >= bd.nrows) v = 1.0;
     }
     w.Dw[cb * RM * RM + lane] = v;
@@ -999,7 +1034,10 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
     } else {
       tt = i < bd.ny ? sigma_at(sy, q) * q[sy.U + sy.NV + bd.obs0 + i] : 0.0;
     }
-    w.JuL[cb * RM * U + e] = tt;
+    (STATE ? pick(sl.JuP, sl_) : w.JuL)[cb * RM * U + e] = tt;
+  }
+  if constexpr (STATE) {
+    for (int e = lane; e < RM * Z; e += 64) w.zbP[cb * RM * Z + e] = zl[e];
   }
 }
 
