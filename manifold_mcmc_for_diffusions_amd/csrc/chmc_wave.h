@@ -3276,6 +3276,137 @@ __device__ __forceinline__ void vm_wait(d2_t (&r)[12]) {
 __device__ __forceinline__ void vm_store16_nt(double* p, const d2_t& v) {
   asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
 }
+// generate_x_obs_seq (:384-397) of every chain's CURRENT state by multiple shooting over the whole chain (one wavefront
+// per chain, 64 segments), seeded with the state's stored trajectory: the states at the observation times for the
+// partition switch.  The stored trajectory is exact inside every block of the CURRENT partition and its block junctions
+// close to the constraint tolerance, so the junction corrections of the first sweep are ~1e-9 and the second sweep only
+// confirms them (settled = every junction moved by rounding at most, as in k_fwd_par); the sequential recursion, 40 000
+// dependent steps on one lane (KXobs: 2 ms per switch at configs[1]), is the fallback.  sy.blk / sy.obs2blk must still
+// describe the partition the trajectory was computed in.
+template <class M>
+__global__ void __launch_bounds__(64) k_xobs_par(Sys sy, Slots sl, double* xobs_out) {
+  constexpr int X = M::X, V = M::V, MAXS = 8;
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x;
+  if (c >= sy.B) return;
+  const int s_ = sl.cur[c];
+  const int S = sy.S, L = sy.T * sy.S;
+  const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
+  const double* trj = pick(sl.traj, s_) + (size_t)c * sy.TRJ;
+  const double* vbase = q + sy.U + sy.V0;
+  double* out = xobs_out + (size_t)c * sy.T * X;
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  double x0[X];
+  M::gx0(cc.z, q + sy.U, x0);
+  const int m = (L + 63) >> 6;
+  const int s0 = lane * m, s1 = (s0 + m < L ? s0 + m : L);
+  const bool have = s0 < L;
+  double Ul[X];
+  {
+    const int b0 = have ? sy.obs2blk[s0 / S] : 0;  // step s of block b sits at trajectory entry s + b
+#pragma unroll
+    for (int a = 0; a < X; ++a) Ul[a] = lane == 0 ? x0[a] : (have ? trj[(size_t)(s0 + b0) * X + a] : 0.0);
+  }
+  bool converged = false;
+  for (int sweep = 0; sweep < MAXS && !converged; ++sweep) {
+    double x[X], P[X * X];
+#pragma unroll
+    for (int a = 0; a < X; ++a) x[a] = Ul[a];
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) P[i] = (i / X == i % X) ? 1.0 : 0.0;
+    for (int s = s0; s < s1; ++s) {
+      double vv[V], A[X * X], Bm[X * V], xn[X], Pn[X * X];
+#pragma unroll
+      for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
+      M::jac_ab(cc.k, x, vv, A, Bm);
+      M::step(cc.k, x, vv, xn);
+      matmul_xx<X>(A, P, Pn);
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) P[i] = Pn[i];
+#pragma unroll
+      for (int a = 0; a < X; ++a) x[a] = xn[a];
+      if ((s + 1) % S == 0) {
+        const int t = (s + 1) / S - 1;
+#pragma unroll
+        for (int a = 0; a < X; ++a) out[t * X + a] = x[a];
+      }
+    }
+    double ec[X], Pc[X * X], Unext[X];
+#pragma unroll
+    for (int a = 0; a < X; ++a) Unext[a] = __shfl_down(Ul[a], 1, 64);
+    const bool junction = have && s1 < L;
+#pragma unroll
+    for (int a = 0; a < X; ++a) ec[a] = junction ? x[a] - Unext[a] : 0.0;
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) Pc[i] = junction ? P[i] : ((i / X == i % X) ? 1.0 : 0.0);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      double Pp[X * X], ep[X], Pn[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Pp[i] = __shfl_up(Pc[i], o, 64);
+#pragma unroll
+      for (int a = 0; a < X; ++a) ep[a] = __shfl_up(ec[a], o, 64);
+      if (lane >= o) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) {
+          double tt = ec[a];
+#pragma unroll
+          for (int d = 0; d < X; ++d) tt += Pc[a * X + d] * ep[d];
+          ec[a] = tt;
+        }
+        matmul_xx<X>(Pc, Pp, Pn);
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Pc[i] = Pn[i];
+      }
+    }
+    double dl[X], Un[X];
+#pragma unroll
+    for (int a = 0; a < X; ++a) {
+      const double up = __shfl_up(ec[a], 1, 64);
+      dl[a] = lane == 0 ? 0.0 : up;
+    }
+    bool still = true;
+#pragma unroll
+    for (int a = 0; a < X; ++a) still = still && dl[a] == 0.0;
+#pragma unroll
+    for (int a = 0; a < X; ++a) {
+      double tt = 0.0;
+#pragma unroll
+      for (int d = 0; d < X; ++d) tt += P[a * X + d] * dl[d];
+      Un[a] = still ? x[a] : x[a] + tt;
+    }
+    int unsettled = 0;
+#pragma unroll
+    for (int a = 0; a < X; ++a) {
+      const double nu = __shfl_up(Un[a], 1, 64);
+      if (lane > 0 && have) {
+        const double old = Ul[a];
+        const bool same = nu == old || (nu != nu && old != old);
+        const bool close = fabs(nu - old) <= 1e-13 * (fabs(nu) > 1.0 ? fabs(nu) : 1.0);
+        unsettled |= !(same || close);
+        Ul[a] = nu;
+      }
+    }
+    converged = __ballot(unsettled) == 0ULL;
+  }
+  if (!converged && lane == 0) {  // sequential recursion
+    double x[X], xn[X];
+#pragma unroll
+    for (int a = 0; a < X; ++a) x[a] = x0[a];
+    for (int s = 0; s < L; ++s) {
+      M::step(cc.k, x, vbase + (size_t)s * V, xn);
+#pragma unroll
+      for (int a = 0; a < X; ++a) x[a] = xn[a];
+      if ((s + 1) % S == 0) {
+        const int t = (s + 1) / S - 1;
+#pragma unroll
+        for (int a = 0; a < X; ++a) out[t * X + a] = x[a];
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <class M, int RM, bool STORE>
