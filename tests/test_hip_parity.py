@@ -4,9 +4,13 @@ Tolerances: the path is fp64 end to end and both sides use the same generated mo
 differences are summation order (Gram / dot-product reductions) and FMA contraction; per-op results must agree
 to 1e-10 relative (inf-norm), single leapfrog steps to 1e-9 relative at identical Newton iteration counts
 (SURVEY.md section 8c)."""
+import os
+import sys
 import numpy as np
 import pytest
 from helpers import make_case, make_ctx, check_ops_against_oracle, check_steps_against_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -610,3 +614,51 @@ def test_sir_variable_noise_boarding_school_s200():
         assert np.abs(p1[c] - po).max() <= 1e-9 * max(1.0, np.abs(po).max())
     assert (res["status"] == 0).sum() >= 4
     ctx.close()
+
+
+_PATH_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from helpers import make_case, make_ctx
+B = 6
+case = make_case({model!r}, {T}, {S}, {R}, True, B=B, seed=77{extra})
+ctx = make_ctx(case)
+rng = np.random.default_rng(5)
+out = {{}}
+for part in range(ctx.num_partition):
+    ctx.set_state(np.repeat(case["q"][:1], B, 0), rng.standard_normal((B, ctx.Q)), np.repeat(case["x_obs"][:1], B, 0), part)
+    ctx.project_onto_cotangent_space()
+    dts = np.where(np.arange(B) % 2 == 0, 1.0, -1.0) * (0.02 + 0.01 * np.arange(B))
+    res = [ctx.leapfrog_step(dts) for _ in range(2)]
+    q, p, xo, _ = ctx.get_state()
+    ctx.switch_partition()
+    q2, p2, xo2, _ = ctx.get_state()
+    out.update({{f"q{{part}}": q, f"p{{part}}": p, f"xo{{part}}": xo2, f"st{{part}}": np.stack([r["status"] for r in res]),
+                f"it{{part}}": np.stack([r["iters_fwd"] + r["iters_bwd"] for r in res]), f"h{{part}}": ctx.hamiltonian()}})
+np.savez({out!r}, **out)
+"""
+
+
+@pytest.mark.parametrize("model,T,S,R,extra", [("fhn", 100, 400, 5, ""), ("sir", 14, 200, 14, ", obs_interval=0.25")])
+def test_compact_row_kernels_agree_with_the_stored_row_kernels_full_size(tmp_path, model, T, S, R, extra):
+    """Two kernel families for the same step at the full BASELINE sizes: the default path (compact rows PB / LF, lean
+    Newton / state / grad-log-det sweeps, two-phase sweep for 16-row blocks, time-parallel x_obs at the partition switch)
+    against the stored-rows kernels of round 1 (every switch off), each in its own process (the switches are read once).
+    Two leapfrog steps per partition and a partition switch: positions, momenta, x_obs to 1e-9 relative, statuses and
+    Newton iteration counts equal."""
+    import subprocess
+    outs = []
+    for name, env in (("compact", {}), ("stored", {"CHMC_COMPACT_ROWS": "0", "CHMC_XOBS_PAR": "0", "CHMC_NEWTON_LEAN": "0",
+                                                      "CHMC_STATE_LEAN": "0", "CHMC_GLD_LEAN": "0"})):
+        out = str(tmp_path / f"{name}.npz")
+        script = _PATH_SCRIPT.format(root=ROOT, tests=os.path.join(ROOT, "tests"), model=model, T=T, S=S, R=R, extra=extra, out=out)
+        r = subprocess.run([sys.executable, "-c", script], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs.append(np.load(out))
+    a, b = outs
+    for k in a.files:
+        if k.startswith(("st", "it")):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        else:
+            scale = max(np.abs(b[k]).max(), 1.0)
+            assert np.abs(a[k] - b[k]).max() <= 1e-9 * scale, (k, np.abs(a[k] - b[k]).max(), scale)
