@@ -18,6 +18,9 @@ SO = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "
                   "libchmc_hip.so")
 
 CLASS_OF = [  # substring of the kernel name -> profiling class of include/chmc.h (first match wins)
+    ("k_newton_lean<chmc::FhnModel, 7, true, true>", "state_blk"), ("k_newton_lean<chmc::FhnModel, 6, true, true>", "state_blk"),
+    ("k_newton_lean<chmc::FhnModel, 8, true, true>", "state_blk"), ("k_newton_lean<chmc::SirModel, 8, true, true>", "state_blk"),
+    ("k_newton_lean<chmc::FhnNbModel, 6, true, true>", "state_blk"), ("k_newton_lean<chmc::FhnNbModel, 8, true, true>", "state_blk"),
     ("k_newton_lean", "newton_blk"), ("k_newton_ivl", "newton_blk"), ("k_newton_comb", "newton_blk"),
     ("k_newton_factor_wave", "sym_blk"), ("k_gram_rows", "newton_blk"), ("KUpdatePB", "update"), ("KMuF", "solve_chain"),
     ("k_jw_pb", "jacob_vec"), ("KRowsFromPB", "state_blk"),
