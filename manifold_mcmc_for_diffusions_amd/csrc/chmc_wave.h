@@ -3,16 +3,19 @@
 // The adjoint recurrence behind the constraint Jacobian (jacob_constr_blocks, sde/mici_extensions.py:521-624)
 //     Lam^(s) = Lam^(s+1) A_s,   dc/dv_s = Lam^(s+1) B_s,   dc/dz += Lam^(s+1) Zf_s
 // is linear in Lam, so a tile of 64 consecutive time steps is processed by the 64 lanes at once:
-//   * lane l loads x_s, v_s of step s = tile_base + l  (unit-stride, 16 B per lane: fully coalesced),
-//   * evaluates its own A_s, B_s, Zf_s,
-//   * a 6-level suffix scan over the lanes (shuffles) forms A_hi ... A_{s+1}, which maps the carried adjoint
-//     rows at the tile end to this lane's step,
-//   * every lane forms its RM x V Jacobian entries, stores them (MODE 0) and accumulates its share of the Gram
-//     block D = Jv Jv'^T in registers (against the stored rows of the previous point in MODE 1),
-//   * lane 0's inclusive product carries the adjoint rows to the next (earlier) tile.
-// Gram / dc/dz partial sums are combined over the wave by a butterfly of shuffles at the end.
-// Compared with one lane per block this turns 7 x 16-byte scattered loads per step per lane into 1 KB
-// contiguous wave loads and gives 64x more lanes of parallelism.
+//   * lane l loads x_s, v_s of one step of the tile (unit-stride, 16 B per lane: fully coalesced; later steps in lower
+//     lanes), evaluates its own A_s, B_s, Zf_s,
+//   * a prefix scan over the lanes on the DPP path of the vector ALU forms the product of the later transition matrices
+//     of the tile (dpp_prefix_products below),
+//   * inside an observation interval every adjoint row is the interval's FRAME (the rows at its end, wave-uniform) times
+//     that row-independent product, so the per-lane work carries no row index: X x Z, X x X running sums, the compact
+//     form PB_s = P_f E_s B_s of the step's Jacobian rows, and the RM-sized products once per interval (k_newton_lean:
+//     Newton iteration and state evaluation; k_newton_ivl / k_newton_comb: the same in two phases for few long blocks;
+//     k_rev_wave: the round-1 formulation with the rows in registers, kept for 16-row blocks and as a fallback),
+//   * the passes over a stored Jacobian (J w, J^T lambda, Gram contraction, grad-log-det weights) read the compact rows
+//     (Slots::PB / LF, chmc_core.h).
+// Compared with one lane per block this turns scattered 16-byte loads per step per lane into 1 KB contiguous wave loads
+// and gives 64x more lanes of parallelism; DESIGN.md section 4 has the measurements.
 #pragma once
 #include <type_traits>
 #include "chmc_core.h"
