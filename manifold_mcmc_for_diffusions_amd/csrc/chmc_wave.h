@@ -1058,8 +1058,12 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
 //            (v_0 columns, observation-noise diagonal, identity padding, dc/du rows through generate_z').
 // Any RM <= 16: no per-lane array is indexed by the row.
 #define CHMC_IVL_N(X, Z) (2 * (X) * (X) + (X) * (Z))
+// (166 VGPRs for FitzHugh-Nagumo: three wavefronts per SIMD at run time; capped at 128 for four it spills, 3x slower)
+#ifndef CHMC_IVL_WAVES
+#define CHMC_IVL_WAVES 2
+#endif
 template <class M>
-__global__ void __launch_bounds__(64, 2) k_newton_ivl(Sys sy, Slots sl, Work w, int which, int qsel) {
+__global__ void __launch_bounds__(64, CHMC_IVL_WAVES) k_newton_ivl(Sys sy, Slots sl, Work w, int which, int qsel) {
   constexpr int X = M::X, V = M::V, Z = M::Z;
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x;

@@ -649,7 +649,7 @@ def test_compact_row_kernels_agree_with_the_stored_row_kernels_full_size(tmp_pat
     import subprocess
     outs = []
     for name, env in (("compact", {}), ("stored", {"CHMC_COMPACT_ROWS": "0", "CHMC_XOBS_PAR": "0", "CHMC_NEWTON_LEAN": "0",
-                                                      "CHMC_STATE_LEAN": "0", "CHMC_GLD_LEAN": "0"})):
+                                                      "CHMC_STATE_LEAN": "0", "CHMC_GLD_LEAN": "0", "CHMC_TWO_PHASE8": "0"})):
         out = str(tmp_path / f"{name}.npz")
         script = _PATH_SCRIPT.format(root=ROOT, tests=os.path.join(ROOT, "tests"), model=model, T=T, S=S, R=R, extra=extra, out=out)
         r = subprocess.run([sys.executable, "-c", script], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
