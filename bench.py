@@ -120,10 +120,19 @@ def cpu_baseline(wl, model, q, p, xo, part, dt, n_steps, solver, gaussian):
         # one chain alone on one core (the reference takes its op timings pinned to a single core,
         # run_fhn_model_noiseless_obs_experiments.sh:115): a quarter of the steps, continuing from chain 0's state
         n1 = max(n // 4, 4)
+        aff = None
+        try:  # pinned to one core, as the reference's `taskset -c 0` does for its op timings
+            aff = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, {min(aff)})
+        except (AttributeError, OSError):
+            aff = None
         t1 = time.perf_counter()
         for _ in range(n1):
             chains[0].step(dt, **kw)
-        return done / el, n1 / (time.perf_counter() - t1), el
+        single = n1 / (time.perf_counter() - t1)
+        if aff is not None:
+            os.sched_setaffinity(0, aff)
+        return done / el, single, el
 
     try:
         v_nat, single_nat, el = timed("native", n_steps)
@@ -138,7 +147,8 @@ def cpu_baseline(wl, model, q, p, xo, part, dt, n_steps, solver, gaussian):
     except OSError:
         pass
     return {"value": v_nat, "unit": "steps/s", "cores": cores, "kind": "port", "cpu_model": model_name,
-            "per_core": v_nat / cores, "single_core_alone": single_nat, "compiler_flags": "gcc " + flags,
+            "per_core": v_nat / cores, "single_core_alone": single_nat, "single_core_pinned": True,
+            "compiler_flags": "gcc " + flags,
             "portable_O2_build": {"value": v_port, "single_core_alone": single_port,
                                   "compiler_flags": "gcc " + c_oracle.PORTABLE_CFLAGS},
             "sample": f"{cores} chains x {n_steps} leapfrog steps from post-burn-in states, C oracle "
@@ -388,48 +398,50 @@ def main():
         else:
             chains_per_launch = float(B)
         mdl = cm.get(name, dict(bytes=8.0 * 3 * ctx.Q, flops=2.0 * ctx.Q))
-        bound = BOUND.get(name, "hbm")
         traffic = traffic_all.get(name)
-        alg_bytes = mdl["bytes"] * chains_per_launch
+        alg_bytes = mdl["bytes"] * chains_per_launch          # SURVEY.md 8(d) operator-level bytes of the launch's chains
+        hbm_bytes = mdl.get("hbm_bytes", mdl["bytes"]) * chains_per_launch  # what the fused kernel has to move
         alg_flops = mdl["flops"] * chains_per_launch
         sec = avg_ms * 1e-3
-        if name == "constr":
-            # the forward scans are sequential recursions, one lane per (chain, block): what binds them is the latency of
-            # the dependent fp64 instructions of one step (tools/ubench/fwd_latency.hip: 36 ns per FitzHugh-Nagumo step)
-            steps = max(b["nsteps"] for b in ctx.blocks[ctx.partition])
-            achieved, unit = steps / sec / 1e6, "Msteps/s per lane"
-            peak = 1e3 / 36.0 if model == "fhn" else None
-            bound = "latency"
-        elif bound == "hbm":
-            # HBM-bound classes are priced on the bytes the kernel has to move given the row-slot layout (structural
-            # zeros skipped, read-modify-write fused); the operator-level figure stays in `algorithmic_bytes_GBs`
-            achieved, peak, unit = mdl.get("hbm_bytes", mdl["bytes"]) * chains_per_launch / sec / 1e9, HBM_PEAK_GBS, "GB/s"
-        else:  # fp64_valu: algorithmic fp64 flops of the launch against the fp64 vector peak
-            achieved, peak, unit = alg_flops / sec / 1e12, FP64_VALU_PEAK_TFLOPS, "TFLOP/s"
+        # HARDWARE fractions of the dominant class: HBM (counter bytes when profiles/traffic.json belongs to this build,
+        # otherwise the bytes the kernel has to move) and fp64 vector flops; `frac` is the larger of the two and `bound`
+        # names it.  The builder-measured latency floor of the forward scan is a secondary figure, not `frac`.
+        hbm_frac_alg = hbm_bytes / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else None
+        hbm_frac_cnt = (traffic / sec / 1e9 / HBM_PEAK_GBS) if (traffic and sec > 0) else None
+        fp64_frac = alg_flops / sec / 1e12 / FP64_VALU_PEAK_TFLOPS if sec > 0 else None
+        hbm_frac = hbm_frac_cnt if hbm_frac_cnt is not None else hbm_frac_alg
+        if (fp64_frac or 0.0) > (hbm_frac or 0.0):
+            bound, achieved, peak, unit, frac = "fp64_valu", alg_flops / sec / 1e12, FP64_VALU_PEAK_TFLOPS, "TFLOP/s", fp64_frac
+        else:
+            bound, achieved, peak, unit, frac = ("hbm", (traffic if hbm_frac_cnt is not None else hbm_bytes) / sec / 1e9,
+                                                 HBM_PEAK_GBS, "GB/s", hbm_frac)
         roofline = {
-            "bound": bound if (bound != "latency" or name == "constr") else "fp64_valu", "kernel": name,
-            "achieved": achieved, "peak": peak, "unit": unit, "frac": (achieved / peak) if peak else None, "traffic": traffic,
-            "hbm_traffic_frac": (traffic / sec / 1e9 / HBM_PEAK_GBS) if traffic else None, "traffic_source": traffic_note,
+            "bound": bound, "kernel": name, "achieved": achieved, "peak": peak, "unit": unit, "frac": frac, "traffic": traffic,
+            "hbm_frac_counters": hbm_frac_cnt, "hbm_frac_bytes_to_move": hbm_frac_alg, "fp64_valu_frac": fp64_frac,
+            "traffic_source": traffic_note,
             "algorithmic_flops_per_launch": alg_flops, "algorithmic_bytes_per_launch": alg_bytes,
-            "algorithmic_bytes_GBs": alg_bytes / sec / 1e9,
+            "bytes_to_move_per_launch": hbm_bytes,
+            "operator_level_byte_rate_GBs_not_a_utilisation": alg_bytes / sec / 1e9 if sec > 0 else None,
             "chains_per_launch": chains_per_launch, "avg_launch_ms": avg_ms, "launches_timed": int(nl[dom]),
             "timed_every": a.profile_stride,
-            "note": "achieved = algorithmic fp64 flops (SURVEY.md 8d: Jacobian sweep + Gram contraction of the launch's "
-                    "chains) / average launch time by HIP events on the library's stream; the kernel regenerates the "
-                    "iterate's Jacobian in registers and is bound by fp64 vector issue, not by HBM (`hbm_traffic_frac` "
-                    "= measured HBM bytes / time / 8 TB/s); `algorithmic_bytes_GBs` is the operator-level byte rate of "
-                    "SURVEY.md 8d, a throughput figure that is NOT a DRAM utilisation (the fused kernel never moves "
-                    "those bytes)" if bound != "hbm" else
-                    "achieved = bytes the launch has to move across HBM (structurally non-zero Jacobian entries + the "
-                    "vectors read and written, for the launch's chains) / average launch time by HIP events on the library's "
-                    "stream; `algorithmic_bytes_GBs` is the operator-level rate of SURVEY.md 8d (dense blocks, unfused "
-                    "operators), a throughput figure that may exceed the HBM peak",
+            "note": "frac = the larger HARDWARE fraction of the dominant kernel class: HBM bytes of the launch (rocprofv3 "
+                    "FETCH/WRITE counters from profiles/traffic.json when that file was produced by this build, else the "
+                    "bytes the fused kernel has to move) / HIP-event launch time / 8 TB/s, or algorithmic fp64 flops "
+                    "(SURVEY.md 8d) / time / 78.6 TFLOP/s.  `operator_level_byte_rate...` prices SURVEY.md 8(d)'s unfused "
+                    "operator decomposition and may exceed the HBM peak: it is a throughput figure, never a utilisation.",
         }
         if name == "constr":
-            roofline["note"] = ("achieved = sequential steps of the longest block / average launch time by HIP events on the "
-                                "library's stream; peak = 1 / (36 ns per step), the dependent-instruction latency floor of one "
-                                "FitzHugh-Nagumo step at one wavefront per SIMD (tools/ubench/fwd_latency.hip); a launch keeps "
-                                "B x K lanes = 80 wavefronts busy, so neither HBM nor the vector pipes bound it")
+            # secondary: the sequential recursion's dependent-instruction latency floor (tools/ubench/fwd_latency.hip,
+            # output kept in profiles/r03_fwd_latency_ubench.txt: 36 ns per FitzHugh-Nagumo step at one wavefront per SIMD)
+            steps = max(b["nsteps"] for b in ctx.blocks[ctx.partition])
+            roofline["sequential_steps_per_launch"] = steps
+            roofline["Msteps_per_s_per_lane"] = steps / sec / 1e6 if sec > 0 else None
+            if model == "fhn":
+                roofline["latency_floor_frac"] = steps * 36e-9 / sec if sec > 0 else None
+                roofline["latency_floor_source"] = "profiles/r03_fwd_latency_ubench.txt (36 ns per step)"
+            roofline["note"] += ("  The forward scans keep B x K lanes = a few dozen wavefronts busy with a sequential "
+                                 "nonlinear recursion, so neither HBM nor the vector pipes are the limit; "
+                                 "`latency_floor_frac` = steps x 36 ns / launch time is the builder-measured ceiling.")
         # the whole step attributed: every class with its time, binding resource and fraction of that resource's peak
         table = {}
         for i, k in enumerate(_lib.KERNEL_CLASSES):
@@ -450,6 +462,12 @@ def main():
                 row["counter_bytes_per_launch"] = traffic_all[k]
                 row["hbm_traffic_frac"] = round(traffic_all[k] / (per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
             table[k] = row
+        # whole step against HBM: sum over classes of counter bytes per launch x launches per step / time / 8 TB/s
+        whole_bytes = whole_frac = None
+        if traffic_all:
+            whole_bytes = float(sum(traffic_all[k] * table[k]["launches_per_step"] for k in table if traffic_all.get(k)))
+            whole_frac = whole_bytes / (t_max / a.steps) / 1e9 / HBM_PEAK_GBS
+        rounds_per_step = (ctx.counters()["projection_iterations"] - iters_before) / max(a.steps, 1)
         out = {
             "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": t_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -462,7 +480,14 @@ def main():
                 "mean_newton_iters_fwd_plus_bwd": k_mean, "step_success_rate": float(agg[0] / agg[1]),
                 "gathered_sample_shape": None if samples is None else list(samples.shape),
                 "bytes_per_chain_step_algorithmic": wl.bytes_per_chain_step(k_mean, newton=wl.solver["newton"]),
-                "whole_path_effective_GBs": wl.bytes_per_chain_step(k_mean, newton=wl.solver["newton"]) * value / 1e9,
+                # SURVEY.md 8(d)'s operator-level bytes x steps/s: NOT a DRAM utilisation (the fused path never moves
+                # those bytes; the figure can exceed the 8 TB/s peak)
+                "operator_level_byte_rate_GBs_not_a_utilisation":
+                    wl.bytes_per_chain_step(k_mean, newton=wl.solver["newton"]) * value / 1e9 / world,
+                "whole_step_counter_bytes": whole_bytes, "whole_step_hbm_frac": whole_frac,
+                "launches_per_step": round(float(sum(nl_w)) / max(a.warmup, 1), 1),
+                "newton_rounds_per_step": rounds_per_step,
+                "collective_backend": D.backend_name(), "collective_world_size": D.world_size(),
                 "overlap_halves": int(os.environ.get("CHMC_HALVES", "-1")),
                 "kernel_classes_warmup": table,
             },

@@ -232,15 +232,26 @@ int chmc_leapfrog_step(chmc_ctx* ctx, const double* dt, const int* active, int n
  *   chmc_gather_samples : local_dev [count] doubles of this rank -> gathered_dev [world][count] on EVERY rank, rank-major
  *                         (equal shards); both are device buffers of the caller; enqueued on the context's stream and
  *                         complete when the call returns
- *   chmc_comm_destroy   : releases the communicator (chmc_destroy does not) */
+ *   chmc_comm_destroy   : releases the communicator (chmc_destroy does the same for a context that still owns one).
+ * N > 1 ranks have been rehearsed with gloo on CPU only so far (tests/test_distributed_gloo.py); see INTEGRATION.md. */
 int chmc_comm_unique_id(void* id128);
 int chmc_comm_init(chmc_ctx* ctx, const void* id128, int rank, int world);
 int chmc_gather_samples(chmc_ctx* ctx, const void* local_dev, long count, void* gathered_dev);
 int chmc_comm_destroy(chmc_ctx* ctx);
 
 /* evaluation counters since creation: {constr, jacob_constr_blocks, lu_jacob_product_blocks, chol_gram_blocks,
- * grad_log_det_sqrt_gram, leapfrog_step calls, newton iteration launches, 0} (cf. _call_counts, :1451-1461) */
+ * grad_log_det_sqrt_gram, leapfrog_step calls, newton iteration launches, 0 (reserved)} (cf. _call_counts, :1451-1461).
+ * Host-side counts: the call does not touch the device. */
 int chmc_get_counters(const chmc_ctx* ctx, long long* out8);
+
+/* diagnostics of the kernel paths taken since creation (tests assert with them that an optional kernel family ran):
+ *   out80[0]       blocks the time-parallel forward scan handed to its sequential fallback
+ *   out80[1 .. 63] histogram of sweeps to convergence of the time-parallel scan (1 + sweeps + 16 (guess kind - 1)), [15] parked
+ *   out80[64]      launches of the fp64-MFMA Gram kernel (v_mfma_f64_16x16x4_f64; 16-row blocks, CHMC_GRAM_MFMA=1)
+ *   out80[65]      launches of the vector-FMA Gram kernel over stored rows (16-row blocks)
+ *   out80[66 .. 79] reserved (0)
+ * Synchronises the context's stream. */
+int chmc_get_diagnostics(chmc_ctx* ctx, long long* out80);
 
 /* ---- measurement: HIP events recorded on the library's own stream around every kernel launch ------------- */
 /* kernel classes: 0 other, 1 newton_blk (constr + Jacobian + Gram/LU of a Newton iteration), 2 state_blk

@@ -75,6 +75,7 @@ SYMBOLS = [
     ("chmc_leapfrog_step", C.c_int, [C.c_void_p, dp, ip, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                      C.c_int, C.c_double, ip, ip, ip, dp]),
     ("chmc_get_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
+    ("chmc_get_diagnostics", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     ("chmc_comm_unique_id", C.c_int, [C.c_void_p]),
     ("chmc_comm_init", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     ("chmc_gather_samples", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),

@@ -337,6 +337,14 @@ class ChmcContext:
     def comm_destroy(self):
         check(self.L.chmc_comm_destroy(self.h), "chmc_comm_destroy")
 
+    def diagnostics(self):
+        """Kernel-path diagnostics (include/chmc.h chmc_get_diagnostics): time-parallel scan counters and launches of the
+        optional kernel families."""
+        out = (C.c_longlong * 80)()
+        check(self.L.chmc_get_diagnostics(self.h, out), "chmc_get_diagnostics")
+        v = np.array(out[:], dtype=np.int64)
+        return dict(par_scan=v[:64], gram_mfma_launches=int(v[64]), gram_valu_launches=int(v[65]))
+
     def counters(self):
         out = (C.c_longlong * 8)()
         check(self.L.chmc_get_counters(self.h, out), "chmc_get_counters")

@@ -395,5 +395,4 @@ extern "C" int chmc_profile_get(double* ms, long long* launches) {
   }
   return 0;
 }
-// HIP events on the library's stream (used by bench.py to time kernels where they are launched)
-extern "C" void* chmc_stream(void) { return (void*)g_stream; }
+

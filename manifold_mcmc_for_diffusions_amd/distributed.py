@@ -81,6 +81,18 @@ def gather_samples(local, dst=0, equal_shards=False):
     return torch.cat(out, 0).cpu().numpy()
 
 
+def world_size():
+    """World size read back from the initialised process group (1 without one)."""
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def backend_name():
+    """Collective backend in use ("nccl" is RCCL on ROCm); None for a single process."""
+    import torch.distributed as dist
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
+
 def max_over_ranks(value):
     import torch
     import torch.distributed as dist

@@ -34,6 +34,16 @@ def test_hip_library_builds_loads_and_exports_every_symbol():
     assert b"gfx950" in blob
 
 
+def test_library_exports_nothing_the_header_does_not_declare():
+    """Every exported chmc_* symbol is part of the declared C ABI (no undeclared debugging entry points)."""
+    import subprocess
+    from manifold_mcmc_for_diffusions_amd import _lib
+    so = _lib.build()
+    out = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("chmc_")})
+    assert exported == header_symbols()
+
+
 def test_no_fallback_without_gpu():
     """Creating a context must fail loudly when no HIP device is visible (this container has none)."""
     import torch

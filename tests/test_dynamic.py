@@ -1,6 +1,7 @@
 """The batched dynamic (no-U-turn, multinomial) transition of dynamic.py against a plain single-chain restatement
 that integrates every sub-tree leaf by leaf and applies the no-U-turn criterion to the aligned binary spans directly
-(the recursive definition), with the same keyed random draws -- through the TEST-ONLY emulation build (CPU)."""
+(the recursive definition), with the same keyed random draws -- through the TEST-ONLY emulation build (CPU) and, under
+`-m gpu`, through the HIP library itself (chmc_tree_step / KTreeDecide / KTreeTurn on the device)."""
 import numpy as np
 from test_emu_logic import emu_lib  # noqa: F401
 
@@ -79,17 +80,32 @@ import pytest  # noqa: E402
 
 @pytest.mark.parametrize("with_metric,extra", [(False, True), (True, True), (False, False)])
 def test_batched_tree_equals_single_chain_restatement(emu_lib, with_metric, extra):  # noqa: F811
+    _tree_vs_restatement(with_metric, extra, b"emu:host-TEST-ONLY")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_metric,extra", [(False, True), (True, True), (False, False)])
+def test_batched_tree_equals_single_chain_restatement_hip(with_metric, extra):
+    """The same on the MI355X: chmc_tree_step's device-side decisions (integrator errors, divergence, multinomial
+    weights, proposal, no-U-turn termination incl. Mici's extra sub-tree checks) against the single-chain restatement,
+    whose leapfrog steps run one chain at a time through the same library."""
+    _tree_vs_restatement(with_metric, extra, b"hip:gfx950", T=12, S=16, R=5, B=5)  # 7-row blocks: the headline kernels
+
+
+def _tree_vs_restatement(with_metric, extra, backend, T=6, S=4, R=2, B=3):
+    from manifold_mcmc_for_diffusions_amd import _lib
+    assert _lib.lib().chmc_backend() == backend
     from manifold_mcmc_for_diffusions_amd import example_models as em
     from manifold_mcmc_for_diffusions_amd.init import fhn_initial_states
     from manifold_mcmc_for_diffusions_amd.context import ChmcContext
     from manifold_mcmc_for_diffusions_amd.dynamic import DynamicTransition, TreeUniforms, _ckpt_range
     assert [_ckpt_range(k)[1] for k in (0, 2, 4, 6)] == [0, 1, 1, 2]              # slot an even leaf is stored in
     assert [_ckpt_range(k) for k in (1, 3, 5, 7)] == [(0, 0), (0, 1), (1, 1), (0, 2)]  # slots an odd leaf is checked against
-    y = em.simulate_fhn_observations(6, 0.2, 50, seed=5, sigma=0.1)
-    B, eps, depth = 3, 0.12, 4
-    ctx = ChmcContext("fhn", 0.2, 4, 2, y[:, 0], sigma=0.1, num_chains=B)
-    ctx1 = ChmcContext("fhn", 0.2, 4, 2, y[:, 0], sigma=0.1, num_chains=1)
-    q, xo, _ = fhn_initial_states(em.fhn, 0.2, 4, y, B, True, seed=7)
+    y = em.simulate_fhn_observations(T, 0.2, 50, seed=5, sigma=0.1)
+    eps, depth = 0.12, 4
+    ctx = ChmcContext("fhn", 0.2, S, R, y[:, 0], sigma=0.1, num_chains=B)
+    ctx1 = ChmcContext("fhn", 0.2, S, R, y[:, 0], sigma=0.1, num_chains=1)
+    q, xo, _ = fhn_initial_states(em.fhn, 0.2, S, y, B, True, seed=7)
     ctx.set_state(q, None, xo, 0)
     W = None
     if with_metric:  # block metric on the global parameters: enters the integrator and the no-U-turn criterion

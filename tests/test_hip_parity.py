@@ -445,6 +445,157 @@ def test_full_size_distinct_chains_with_masked_subset():
     ctx.close()
 
 
+def _step_every_chain_against_oracle(ctx, osys, q, p0, xo, part, dts, act, max_iters, tol=1e-9):
+    """One batched leapfrog step from the given per-chain states against one oracle chain per chain."""
+    from oracle import c_oracle
+    B = len(q)
+    res = ctx.leapfrog_step(dts, active=act, max_iters=max_iters)
+    q1, p1, _, _ = ctx.get_state()
+    n_ok, edge = 0, []
+    for c in range(B):
+        if not act[c]:
+            assert res["status"][c] == -1 and np.array_equal(q1[c], q[c]) and np.array_equal(p1[c], p0[c]), (part, c)
+            continue
+        ch = c_oracle.OracleChain(osys)
+        ch.set(q[c], p0[c], xo[c], part)
+        st, itf, itb, _ = ch.step(dts[c], max_iters=max_iters)
+        qo, po, _, _ = ch.get()
+        assert res["status"][c] == st, (part, c, res["status"][c], st)
+        same_counts = res["iters_fwd"][c] == itf and (st != 0 or res["iters_bwd"][c] == itb)
+        ctol = tol
+        if not same_counts:
+            # Only acceptable on the EDGE of a convergence tolerance (Newton residuals a few ulps either side of ctol / ptol
+            # between two correct evaluation orders): the oracle itself must reproduce the library's counts with its
+            # tolerances moved by a factor 1.5 either way, and the two results then differ by less than position_tol.
+            got = (int(res["iters_fwd"][c]), int(res["iters_bwd"][c]))
+            seen = set()
+            for f in (1.5, 1.0 / 1.5):
+                ch2 = c_oracle.OracleChain(osys)
+                ch2.set(q[c], p0[c], xo[c], part)
+                s2, f2, b2, _ = ch2.step(dts[c], max_iters=max_iters, ctol=1e-9 * f, ptol=1e-8 * f)
+                seen.add((f2, b2 if s2 == 0 else got[1]))
+            assert st == 0 and got in seen, (part, c, got, (itf, itb), seen)
+            edge.append(c)
+            ctol = 1e-7
+        assert np.abs(q1[c] - qo).max() <= ctol * max(1.0, np.abs(qo).max()), (part, c)
+        assert np.abs(p1[c] - po).max() <= ctol * max(1.0, np.abs(po).max()), (part, c)
+        n_ok += st == 0
+    assert len(edge) <= max(1, B // 30), edge  # tolerance-edge chains are rare
+    return res, n_ok
+
+
+def _spread_chains_by_stepping(ctx, case, part, rng, n_pre=2):
+    """B DIFFERENT on-manifold states for data sets where they cannot be written down (noiseless observations: every
+    chain has to reproduce the same observed path exactly): start every chain from chain 0's on-manifold state with its
+    own momentum and step size and move it n_pre leapfrog steps with the library.  The states read back are then the
+    common INPUT of the library and of the oracle for the step that is compared."""
+    B = case["B"]
+    ctx.set_state(np.repeat(case["q"][:1], B, 0), rng.standard_normal((B, ctx.Q)), np.repeat(case["x_obs"][:1], B, 0), part)
+    ctx.project_onto_cotangent_space()
+    pre = np.where(np.arange(B) % 2 == 0, 1.0, -1.0) * (0.03 + 0.05 * rng.random(B))
+    for _ in range(n_pre):
+        r = ctx.leapfrog_step(pre)
+        assert (r["status"] == 0).mean() > 0.9
+    q, _, xo, _ = ctx.get_state()
+    assert np.abs(q - q[:1]).max(1).min(initial=np.inf, where=np.arange(B) > 0) > 1e-3  # the chains have moved apart
+    return q, xo
+
+
+@pytest.mark.parametrize("name,model,T,S,R,noisy,obs_interval", [
+    ("configs[2] FHN noiseless S=400", "fhn", 100, 400, 5, False, None),
+    ("configs[4] shape FHN noisy S=800", "fhn", 100, 800, 5, True, None),
+    ("configs[3] shape SIR S=200 one block", "sir", 14, 200, 14, True, 0.25)])
+def test_full_size_distinct_chains_other_baseline_shapes(name, model, T, S, R, noisy, obs_interval):
+    """The full-size check of configs[1] (test_full_size_distinct_chains_with_masked_subset) for the other BASELINE
+    shapes: 72 DISTINCT chains (full and partial wavefronts of every kernel; the SIR single-block layout runs the
+    time-parallel scan with chains that need different numbers of sweeps), a subset masked out, two chains whose
+    retraction cannot converge -- every chain against the C oracle, in every partition."""
+    B = 72
+    rng = np.random.default_rng(72)
+    if noisy:
+        case = _distinct_on_manifold_chains(model, T, S, R, B, seed=73, obs_interval=obs_interval)
+    else:
+        case = make_case(model, T, S, R, noisy, B=B, seed=73, obs_interval=obs_interval)
+    ctx = make_ctx(case)
+    inactive, failing = [5, 17, 33, 64, 71], [7, 40]
+    for part in range(ctx.num_partition):
+        if noisy:
+            q, xo = case["q"], case["x_obs"]
+        else:
+            q, xo = _spread_chains_by_stepping(ctx, case, part, rng)
+        ctx.set_state(q, rng.standard_normal((B, ctx.Q)), xo, part)
+        assert np.abs(ctx.constr()).max() < 1e-8
+        ctx.project_onto_cotangent_space()
+        _, p0, _, _ = ctx.get_state()
+        h = 0.02 if model == "sir" else 0.04
+        dts = np.where(np.arange(B) % 2 == 0, 1.0, -1.0) * (0.5 * h + h * rng.random(B))
+        dts[failing] = 5.0
+        act = np.ones(B, dtype=np.int32)
+        act[inactive] = 0
+        res, n_ok = _step_every_chain_against_oracle(ctx, case["osys"], q, p0, xo, part, dts, act, max_iters=12)
+        assert (res["status"][failing] > 0).all()
+        assert n_ok >= B - len(inactive) - len(failing) - 4, (name, part, n_ok)
+    ctx.close()
+
+
+_MFMA_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from helpers import check_ops_against_oracle
+from oracle import c_oracle
+from manifold_mcmc_for_diffusions_amd.workload import SirWorkload
+B = 6
+wl = SirWorkload(B, num_steps_per_obs=200)
+ctx = wl.ctx
+assert ctx.RM == 16 and ctx.K == [1]
+q, _, xo, _ = ctx.get_state()
+osys = c_oracle.OracleSystem("sir", 1.0, 200, 14, wl.y[:, 0], sigma=1.0)
+case = dict(osys=osys, q=q, x_obs=xo, B=B, rng=np.random.default_rng(5))
+worst = check_ops_against_oracle(ctx, case, tol=1e-9)
+ctx.set_state(q, case["rng"].standard_normal((B, ctx.Q)), xo, 0)
+ctx.project_onto_cotangent_space()
+_, p0, _, _ = ctx.get_state()
+dts = np.array([0.05, -0.05, 0.1, -0.1, 0.02, 0.2])
+d0 = ctx.diagnostics()
+res = ctx.leapfrog_step(dts)
+d1 = ctx.diagnostics()
+q1, p1, _, _ = ctx.get_state()
+n_ok = 0
+for c in range(B):
+    ch = c_oracle.OracleChain(osys)
+    ch.set(q[c], p0[c], xo[c], 0)
+    st, itf, itb, _ = ch.step(dts[c])
+    qo, po, _, _ = ch.get()
+    assert res["status"][c] == st and res["iters_fwd"][c] == itf and (st != 0 or res["iters_bwd"][c] == itb), c
+    assert np.abs(q1[c] - qo).max() <= 1e-9 * max(1.0, np.abs(qo).max()), c
+    assert np.abs(p1[c] - po).max() <= 1e-9 * max(1.0, np.abs(po).max()), c
+    n_ok += st == 0
+assert n_ok >= 4
+iters = int(res["iters_fwd"].max() + res["iters_bwd"].max())
+print("MFMA_LAUNCHES", d1["gram_mfma_launches"], d1["gram_mfma_launches"] - d0["gram_mfma_launches"],
+      "VALU_LAUNCHES", d1["gram_valu_launches"], "ITERS", iters, "CHOL_D", worst["chol_D"])
+"""
+
+
+def test_fp64_mfma_gram_kernel_boarding_school_sir():
+    """BASELINE.json configs[4] names an fp64-MFMA J J^T Gram build.  The kernel (k_gram_rows_mfma,
+    v_mfma_f64_16x16x4_f64 over the stored rows of 16-row blocks) is optional -- the vector-FMA kernel is faster on this
+    part -- so it is run here in a child process with CHMC_GRAM_MFMA=1 CHMC_COMPACT16=0 (the
+    stored-rows Newton sweep, the only path that forms a Gram block from rows): every per-op entry point (chol_D is the
+    factor of the MFMA-built Gram) and one leapfrog step of the boarding-school SIR chains against the C oracle, and the
+    library's own launch counters must show that the MFMA kernel, not the vector kernel, did the work."""
+    import subprocess
+    script = _MFMA_SCRIPT.format(root=ROOT, tests=os.path.join(ROOT, "tests"))
+    env = {**os.environ, "CHMC_GRAM_MFMA": "1", "CHMC_COMPACT16": "0"}
+    r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("MFMA_LAUNCHES")][-1].split()
+    total, in_step, valu, iters = int(line[1]), int(line[2]), int(line[4]), int(line[6])
+    assert valu == 0, line            # the vector-FMA Gram kernel never ran
+    assert in_step >= iters + 1, line  # one MFMA Gram per Newton iteration of the step + the state evaluation
+    assert total > in_step, line      # ... and the state evaluations of the per-op checks
+
+
 def test_sir_boarding_school_s200_adam_init_against_oracle():
     """BASELINE.json configs[3] as scripts/sir_model_chmc_experiment.py sets it up: the boarding-school counts, S = 200,
     ONE sub-sequence of R = 14 observations (16-row kernels), sigma_y = 1, initial states by the Adam-based finder of the

@@ -48,7 +48,5 @@ for r in range(rounds):
 import ctypes as C
 from manifold_mcmc_for_diffusions_amd import _lib
 L = _lib.lib()
-L.chmc_debug_par_scan.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
-cnt = (C.c_int * 64)()
-L.chmc_debug_par_scan(b.h, cnt)
+cnt = b.diagnostics()["par_scan"]
 print(tot, "sequential fallbacks", cnt[0])

@@ -11,13 +11,10 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 dt = float(sys.argv[3]) if len(sys.argv) > 3 else 0.25
 wl = SirWorkload(B, num_steps_per_obs=S)
 L = _lib.lib()
-L.chmc_debug_par_scan.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
 
 
 def counters():
-    a = (C.c_int * 64)()
-    L.chmc_debug_par_scan(wl.ctx.h, a)
-    return np.array(a[:])
+    return wl.ctx.diagnostics()["par_scan"].copy()
 
 
 for it in range(4):

@@ -4,7 +4,10 @@ prescribes: `rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d DI
 per-launch HBM traffic per kernel class -> profiles/traffic.json (read by bench.py for `roofline.traffic`).
 
 Units / corrections (guide, section HBM): counters are in KB; on gfx950 FETCH_SIZE reports half of the bytes of a
-wide (16 B / lane) coalesced streaming read, so it is doubled; WRITE_SIZE is taken as is.
+wide (16 B / lane) coalesced streaming read; other access patterns are calibrated on this library's own patterns
+(tools/ubench/fetch_calib.hip -> profiles/fetch_calibration.json: bytes read / FETCH_SIZE per pattern, and which pattern
+each kernel class follows); the factor used per class is recorded in the output (2.0 when no calibration file exists).
+WRITE_SIZE is taken as is.
 The output records the SHA-256 of the library that was profiled (`_lib_sha256`), the bench configuration and the
 command, and bench.py quotes `roofline.traffic` from it only when they match the build it is timing.
 usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [config] [command]"""
@@ -49,21 +52,42 @@ def per_class(path, counter):
     return out
 
 
+def fetch_factors():
+    """FETCH_SIZE correction per kernel class from the calibration run (profiles/fetch_calibration.json)."""
+    path = os.path.join(os.path.dirname(SO), "..", "profiles", "fetch_calibration.json")
+    try:
+        cal = json.load(open(path))
+    except (OSError, ValueError):
+        return {}, "no calibration file: factor 2.0 (the guide's 16-B-per-lane figure) for every class"
+    fac = {}
+    for cls, pat in cal.get("class_pattern", {}).items():
+        v = cal.get("factor", {}).get(pat)
+        if v:
+            fac[cls] = float(v)
+    return fac, "profiles/fetch_calibration.json (tools/ubench/fetch_calib.hip on this GPU)"
+
+
 def main():
     f = per_class(sys.argv[1], "FETCH_SIZE")
     w = per_class(sys.argv[2], "WRITE_SIZE")
-    res = {"_method": "bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the launches of the "
-                      "class; FETCH_SIZE doubled per the gfx950 correction for 16-B-per-lane coalesced reads; two "
-                      "separate rocprofv3 --pmc passes of `bench.py --steps 4 --warmup 2`"}
+    fac, fac_src = fetch_factors()
+    res = {"_method": "bytes per launch = (factor * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the launches of the "
+                      "class; factor = calibrated bytes-per-FETCH_SIZE of the class's access pattern (`_fetch_factor`); "
+                      "two separate rocprofv3 --pmc passes of `bench.py --steps 4 --warmup 2`",
+           "_fetch_factor": {}, "_fetch_factor_source": fac_src}
     res["_lib_sha256"] = hashlib.sha256(open(SO, "rb").read()).hexdigest()
     res["_config"] = sys.argv[4] if len(sys.argv) > 4 else "fhn_noisy"
     res["_command"] = sys.argv[5] if len(sys.argv) > 5 else "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 2"
     for cls in sorted(set(f) | set(w)):
         fs, fn = f.get(cls, (0.0, 1))
         ws, wn = w.get(cls, (0.0, 1))
-        res[cls] = (2.0 * fs / max(fn, 1) + ws / max(wn, 1)) * 1024.0
+        k = fac.get(cls, 2.0)
+        res["_fetch_factor"][cls] = k
+        res[cls] = (k * fs / max(fn, 1) + ws / max(wn, 1)) * 1024.0
         res[cls + "_detail"] = {"fetch_KB_raw": fs / max(fn, 1), "write_KB": ws / max(wn, 1), "launches": fn}
     json.dump(res, open(sys.argv[3], "w"), indent=1)
+    # launches per class in the profiled command (for the whole-step sum of bench.py)
+    res["_launches"] = {cls: int(max(f.get(cls, (0, 0))[1], w.get(cls, (0, 0))[1])) for cls in set(f) | set(w)}
     print(json.dumps({k: v for k, v in res.items() if not k.endswith("_detail") and not k.startswith("_")}, indent=1))
 
 
