@@ -55,6 +55,12 @@ def parse():
     ap.add_argument("--burn-iters", type=int, default=5)
     ap.add_argument("--burn-steps", type=int, default=16)
     ap.add_argument("--burn-step-size", type=float, default=None)
+    ap.add_argument("--lockstep", action="store_true",
+                    help="one chmc_leapfrog_step call per step with the trajectory bookkeeping on the host instead of one "
+                         "chmc_leapfrog_steps call per trajectory (same batched steps underneath unless --engine async)")
+    ap.add_argument("--engine", default="lockstep", choices=["lockstep", "async"],
+                    help="implementation behind chmc_leapfrog_steps: lock-step batched steps (default) or the asynchronous "
+                         "per-chain-phase engine (sets CHMC_ASYNC=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="record no HIP events in the timed region")
     ap.add_argument("--profile-stride", type=int, default=1,
@@ -246,6 +252,8 @@ def _class_model_operator(nnz, Q, jac, gram_ns, gram_sym, f, n_s):
 
 def main():
     a = parse()
+    if a.engine == "async":
+        os.environ["CHMC_ASYNC"] = "1"
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         spawn_ranks(a)
     from manifold_mcmc_for_diffusions_amd import distributed as D
@@ -302,16 +310,40 @@ def main():
         ctx.switch_partition()
 
     def run_steps(n, stats=None):
+        """n batched leapfrog steps = n / traj_len trajectories.  Between trajectories: IndependentMomentumTransition +
+        SwitchPartitionTransition.  A trajectory is ONE chmc_leapfrog_steps call (each chain takes its traj_len steps at its
+        own pace; an integrator error ends that chain's trajectory, as in Mici's integration transitions), or with
+        --lockstep one batched chmc_leapfrog_step per step with the same bookkeeping on the host."""
         k = run_steps.k
-        for _ in range(n):
-            if k % a.traj_len == 0:  # IndependentMomentumTransition + SwitchPartitionTransition between trajectories
+        done = 0
+        while done < n:
+            if k % a.traj_len == 0:
                 if k:
                     ctx.switch_partition()
                 wl.refresh_momentum()  # device-side Philox stream + projection
-            r = wl.step(step_size)
-            k += 1
-            if stats is not None:
-                stats.append(r)
+                run_steps.act = np.ones(B, dtype=np.int32)
+            m = min(a.traj_len - k % a.traj_len, n - done)
+            if a.lockstep:
+                for _ in range(m):
+                    r = wl.step(step_size, active=run_steps.act)
+                    on = run_steps.act == 1
+                    if stats is not None:
+                        stats.append(dict(attempted=int(on.sum()), ok=int((r["status"][on] == 0).sum()),
+                                          iters=int(r["iters_fwd"][on].sum() + r["iters_bwd"][on].sum()),
+                                          iters_ok=int((r["iters_fwd"] + r["iters_bwd"])[on & (r["status"] == 0)].sum()),
+                                          steps_clean=int((on & (r["status"] == 0)).sum())))
+                    run_steps.act &= (r["status"] == 0).astype(np.int32)
+            else:
+                r = ctx.leapfrog_steps(step_size, m, active=run_steps.act, **wl.solver)
+                on = run_steps.act == 1
+                if stats is not None:
+                    stats.append(dict(attempted=int((r["n_done"][on] + (r["status"][on] > 0)).sum()), ok=int(r["n_done"][on].sum()),
+                                      iters=int(r["iters_fwd"][on].sum() + r["iters_bwd"][on].sum()),
+                                      iters_ok=int((r["iters_fwd"] + r["iters_bwd"])[on & (r["status"] == 0)].sum()),
+                                      steps_clean=int(r["n_done"][on & (r["status"] == 0)].sum())))
+                run_steps.act &= (r["status"] == 0).astype(np.int32)
+            k += m
+            done += m
         run_steps.k = k
 
     run_steps.k = 0
@@ -357,14 +389,16 @@ def main():
     t_max = D.max_over_ranks(elapsed)
     per_rank = D.gather_samples(np.array([[elapsed * 1e3]]), equal_shards=True)
 
-    status = np.stack([s["status"] for s in stats])
-    okm = status == 0
-    itf = np.stack([s["iters_fwd"] for s in stats])
-    itb = np.stack([s["iters_bwd"] for s in stats])
-    k_mean = float((itf[okm] + itb[okm]).mean()) if okm.any() else float("nan")
-    agg = D.sum_over_ranks([okm.sum(), status.size, itf.sum() + itb.sum(), 1.0])
+    attempted = float(sum(x["attempted"] for x in stats))
+    n_ok = float(sum(x["ok"] for x in stats))
+    iters_all = float(sum(x["iters"] for x in stats))
+    n_clean = float(sum(x["steps_clean"] for x in stats))
+    k_mean = (sum(x["iters_ok"] for x in stats) / n_clean) if n_clean else float("nan")  # (steps of calls without a failure)
+    agg = D.sum_over_ranks([n_ok, attempted, iters_all, 1.0])
     if rank == 0:
-        total_steps = world * B * a.steps
+        # chain-steps actually attempted: a chain whose step fails ends its trajectory ("failed steps count
+        # as work done and end that chain's trajectory"); with every step succeeding this is chains x steps
+        total_steps = float(agg[1])
         value = total_steps / t_max
         cm = class_model(ctx, wl, model, wl.solver["newton"])
         # measured HBM bytes per launch of every class (two separate rocprofv3 --pmc passes, tools/pmc_summary.py);
@@ -387,7 +421,7 @@ def main():
         name = _lib.KERNEL_CLASSES[dom]
         avg_ms = ms[dom] / max(nl[dom], 1) if nl[dom] else float("nan")
         launches_all = nl[dom] * a.profile_stride
-        pairs = float(itf.sum() + itb.sum())  # (chain, Newton iteration) pairs of the timed region
+        pairs = iters_all  # (chain, Newton iteration) pairs of the timed region
         if name == "newton_blk" and nl[dom]:
             chains_per_launch = pairs / launches_all
         elif name in ("update", "constr", "solve_chain", "sym_blk") and nl[dom]:
@@ -475,6 +509,9 @@ def main():
             "config": {
                 "workload": workload, "chains_per_gpu": B, "global_chains": world * B, "dim_q": ctx.Q,
                 "step_size": step_size, "traj_len": a.traj_len,
+                "stepping": ("chmc_leapfrog_step per step, host bookkeeping" if a.lockstep else
+                             "chmc_leapfrog_steps per trajectory, " + ("asynchronous per-chain phases" if os.environ.get("CHMC_ASYNC") == "1" else "lock-step batched steps")),
+                "chain_steps_attempted": total_steps, "chain_steps_nominal": world * B * a.steps,
                 "parallelism": f"chains x{world} (no data-path collective, 1 gather)",
                 "ranks_joined": int(agg[3]), "per_rank_ms": None if per_rank is None else [round(float(x), 2) for x in per_rank[:, 0]],
                 "mean_newton_iters_fwd_plus_bwd": k_mean, "step_success_rate": float(agg[0] / agg[1]),

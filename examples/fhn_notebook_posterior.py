@@ -121,12 +121,15 @@ def run(num_chains=64, n_iter=700, n_warm=200, n_step=24, out_dir=None, seed=202
         # diagnosis of the chains left out: where their parameters sit and how their transitions ended
         sm_all = summarize({k: v[:, n_warm:] for k, v in tr.items()})
         print("chains left out of the summary (moved in < 10 % of the main transitions, or still drifting: first fifth vs second half > 4 sd):")
-        oc = res.get("chain_outcomes")
+        oc, od = res.get("chain_outcomes"), res.get("chain_outcomes_dynamic")
         for c in np.flatnonzero(~moving):
             line = f"  chain {c:3d}: sigma {tr['σ'][c, -1]:.3f} eps {tr['ϵ'][c, -1]:.4f} gamma {tr['γ'][c, -1]:.3f} beta {tr['β'][c, -1]:.3f}"
             if oc is not None:
                 line += ("  transitions: accepted %d, rejected %d, not converged %d, diverged %d, non-reversible %d"
                          % tuple(oc[c]))
+            if od is not None:
+                line += ("  trees: moved %d, not moved %d, ended by integrator error %d, by divergence %d, no leaf at all %d, "
+                         "non-finite root energy %d; mean leaves %.1f" % (*od[c], res["per_chain"]["n_step"][c]))
             print(line)
         print("  posterior means over ALL chains (no selection): " + ", ".join(
             f"{k} {sm_all['mean'][k]:.3f}" for k in ("σ", "ϵ", "γ", "β", "x_0[0]", "x_0[1]")))
@@ -136,6 +139,11 @@ def run(num_chains=64, n_iter=700, n_warm=200, n_step=24, out_dir=None, seed=202
         zscore = (sm["mean"][k] - ref["mean"][k]) / np.hypot(mc, ref["mcse_mean"][k])
         rows.append(dict(var=k, mean=sm["mean"][k], sd=sm["sd"][k], r_hat=sm["r_hat"][k], ess=sm["ess_bulk"][k],
                          ref_mean=ref["mean"][k], ref_sd=ref["sd"][k], z=zscore))
+    if verbose and transition == "dynamic":
+        pc = res["per_chain"]
+        print("  sampler statistics over the chains of the summary only (the pooled figures below average the left-out chains in): "
+              f"accept {pc['accept'][moving].mean():.2f}, leaves per tree {pc['n_step'][moving].mean():.1f}, trees ended by an "
+              f"integrator error or divergence {pc['err'][moving].mean():.3f}")
     if verbose:
         print(f"{int(moving.sum())} of {num_chains} chains moving in the main phase (summary over those)")
         print(f"{num_chains} chains x {n_iter} transitions x <= {n_step} steps in {el:.1f} s; final step size "

@@ -222,6 +222,27 @@ int chmc_leapfrog_step(chmc_ctx* ctx, const double* dt, const int* active, int n
                        double constraint_tol, double position_tol, double divergence_tol, int max_iters,
                        double reverse_check_tol, int* status, int* iters_fwd, int* iters_bwd, double* rev_err);
 
+/* A whole integration trajectory per chain: up to n_steps[c] (n_steps == NULL: n_steps_all for every chain) consecutive
+ * ConstrainedLeapfrogIntegrator.step calls of the chains with active[c] != 0, the loop a Mici integration transition
+ * runs around integrator.step (mici.transitions: `for s in range(n_step): state = integrator.step(state)`, ended by
+ * an IntegratorError; scripts/utils.py:284-301).  Semantics per chain = chmc_leapfrog_step applied repeatedly: a chain
+ * whose step fails keeps the state its last successful step produced, reports that step's status and takes no further
+ * steps.  Outputs [B]: n_done (successful steps), status (0: all steps done; 1 / 2 / 3: the failing step's code; -1:
+ * inactive), iters_fwd / iters_bwd (Newton iterations summed over the chain's steps, the failing one included), rev_err
+ * (reverse-check distance of the last step that reached the check).
+ * Two implementations of these semantics, same per-chain arithmetic (same kernels), tested bitwise equal:
+ *  - lock-step (default): one batched chmc_leapfrog_step per step over the chains still running;
+ *  - CHMC_ASYNC=1 (environment, read per call; needs n_inner_step == 1 and momenta known to be in the cotangent space):
+ *    the asynchronous engine -- every chain moves through the phases of its steps (half-kick + flow, forward retraction,
+ *    state evaluation, reverse retraction, check + half-kick) at its own pace, as the reference's sequential per-chain
+ *    loops do (lax.while_loop :1119-1131 iterates as long as THAT chain needs); the batch only shares kernel launches
+ *    and the state evaluations run on a second stream beside the retractions.  Measured slower than lock-step at the
+ *    BASELINE shapes so far, hence not the default. */
+int chmc_leapfrog_steps(chmc_ctx* ctx, const double* dt, const int* active, const int* n_steps, int n_steps_all,
+                        int n_inner_step, int newton, double constraint_tol, double position_tol, double divergence_tol,
+                        int max_iters, double reverse_check_tol, int* n_done, int* status, int* iters_fwd, int* iters_bwd,
+                        double* rev_err);
+
 /* The single collective of a chain-sharded run: chains are independent, every rank (one process per
  * GPU) steps its own contiguous shard with no communication, and a sampling segment ends with ONE all-gather of the
  * traced per-chain samples over RCCL / xGMI.  (The reference runs its chains sequentially in one process,

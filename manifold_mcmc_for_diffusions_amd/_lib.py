@@ -74,6 +74,8 @@ SYMBOLS = [
                                dp, dp, ip]),
     ("chmc_leapfrog_step", C.c_int, [C.c_void_p, dp, ip, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                      C.c_int, C.c_double, ip, ip, ip, dp]),
+    ("chmc_leapfrog_steps", C.c_int, [C.c_void_p, dp, ip, ip, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                      C.c_double, C.c_int, C.c_double, ip, ip, ip, ip, dp]),
     ("chmc_get_counters", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     ("chmc_get_diagnostics", C.c_int, [C.c_void_p, C.POINTER(C.c_longlong)]),
     ("chmc_comm_unique_id", C.c_int, [C.c_void_p]),

@@ -42,6 +42,7 @@ class ChmcContext:
         self.noisy = sigma is not None
         self.variable_sigma = isinstance(sigma, str)
         self.sigma = sigma
+        self.device = int(device)
         self.partition = 0
         self.blocks = []
         keys = ("obs0", "nobs", "first", "last", "row0", "nrows", "ny", "col0", "ncols", "step0", "nsteps", "_")
@@ -315,6 +316,23 @@ class ChmcContext:
                                         position_tol, divergence_tol, int(max_iters), reverse_check_tol, iptr(status),
                                         iptr(itf), iptr(itb), ptr(rev)), "chmc_leapfrog_step")
         return dict(status=status, iters_fwd=itf, iters_bwd=itb, rev_err=rev)
+
+    def leapfrog_steps(self, dt, n_steps, active=None, n_inner_step=1, newton=True, constraint_tol=1e-9, position_tol=1e-8,
+                       divergence_tol=1e10, max_iters=50, reverse_check_tol=2e-8):
+        """Whole trajectories: up to n_steps (an int, or one int per chain) consecutive integrator steps per chain, every
+        chain at its own pace; a chain's trajectory ends at its first failed step (include/chmc.h chmc_leapfrog_steps).
+        Returns n_done, status (0, or the failing step's code; -1 inactive), summed iters_fwd / iters_bwd, rev_err."""
+        dt = as_c(np.broadcast_to(np.asarray(dt, dtype=np.float64), (self.B,)))
+        act = None if active is None else np.ascontiguousarray(active, dtype=np.int32)
+        per_chain = None if np.isscalar(n_steps) else np.ascontiguousarray(np.broadcast_to(n_steps, (self.B,)), dtype=np.int32)
+        n_all = int(n_steps) if per_chain is None else 0
+        ndone, status = np.zeros(self.B, dtype=np.int32), np.zeros(self.B, dtype=np.int32)
+        itf, itb = np.zeros(self.B, dtype=np.int32), np.zeros(self.B, dtype=np.int32)
+        rev = np.zeros(self.B)
+        check(self.L.chmc_leapfrog_steps(self.h, ptr(dt), iptr(act), iptr(per_chain), n_all, int(n_inner_step), int(newton),
+                                         constraint_tol, position_tol, divergence_tol, int(max_iters), reverse_check_tol,
+                                         iptr(ndone), iptr(status), iptr(itf), iptr(itb), ptr(rev)), "chmc_leapfrog_steps")
+        return dict(n_done=ndone, status=status, iters_fwd=itf, iters_bwd=itb, rev_err=rev)
 
     # ---- the one collective of a chain-sharded run, through the library's own RCCL binding (include/chmc.h)
     def comm_init(self, id128, rank, world):

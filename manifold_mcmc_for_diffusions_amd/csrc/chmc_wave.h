@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];  // work order: longest blocks first
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (MODE == 1 ? w.nw[c] != 1 : !w.ok[c]) return;
+  if (MODE == 1 ? !newton_select(w, c, which, qsel) : !w.ok[c]) return;
   const BlockDesc bd = sy.blk[b];
   const int sl_ = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];  // work order: longest blocks first
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (STATE ? !w.ok[c] : w.nw[c] != 1) return;
+  if (STATE ? !w.ok[c] : !newton_select(w, c, which, qsel)) return;
   const BlockDesc bd = sy.blk[b];
   const int sl_ = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
@@ -1071,7 +1071,7 @@ __global__ void __launch_bounds__(64, CHMC_IVL_WAVES) k_newton_ivl(Sys sy, Slots
   const int m = wid % sy.NOBS;
   const int cbi = sy.order[wid / sy.NOBS];
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (w.nw[c] != 1) return;
+  if (!newton_select(w, c, which, qsel)) return;
   const BlockDesc bd = sy.blk[b];
   if (m >= bd.nobs) return;
   const int sl_ = sl.cur[c] ^ which;
@@ -1198,7 +1198,7 @@ __global__ void __launch_bounds__(64) k_newton_comb(Sys sy, Slots sl, Work w, in
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (w.nw[c] != 1) return;
+  if (!newton_select(w, c, which, qsel)) return;
   const BlockDesc bd = sy.blk[b];
   const int sl_ = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
@@ -1338,7 +1338,7 @@ __global__ void __launch_bounds__(64) k_rev_wave_ldsrows(Sys sy, Slots sl, Work 
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (MODE == 1 ? w.nw[c] != 1 : !w.ok[c]) return;
+  if (MODE == 1 ? !newton_select(w, c, which, qsel) : !w.ok[c]) return;
   const BlockDesc bd = sy.blk[b];
   const int sl_ = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
@@ -1545,7 +1545,7 @@ __global__ void __launch_bounds__(256) k_gram_rows(Sys sy, Slots sl, Work w, int
   const int g = wid % NG;
   const int cbi = sy.order[wid / NG];
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (newton ? w.nw[c] != 1 : !w.ok[c]) return;
+  if (newton ? !newton_select(w, c, which, qsel) : !w.ok[c]) return;
   const BlockDesc bd = sy.blk[b];
   const int s = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
@@ -1614,7 +1614,7 @@ __global__ void __launch_bounds__(64) k_gram_rows_mfma(Sys sy, Slots sl, Work w,
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (newton ? w.nw[c] != 1 : !w.ok[c]) return;
+  if (newton ? !newton_select(w, c, which, qsel) : !w.ok[c]) return;
   const BlockDesc bd = sy.blk[b];
   const int s = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
@@ -3050,7 +3050,7 @@ __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (c >= sy.B) return;
-  if (TGT == 0 ? w.nw[c] != 1 : !w.ok[c]) return;
+  if (TGT == 0 ? !newton_select(w, c, which, qsel) : !w.ok[c]) return;
   const int s = sl.cur[c] ^ which;
   const bool has = lane < sy.K;
   const size_t cb = (size_t)c * sy.Kmax + (has ? lane : 0);
@@ -3142,6 +3142,138 @@ __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Newton iteration, everything between the Gram blocks and the J^T lambda column pass in ONE launch (blocks of at most 8
+// rows, at most 64 blocks per chain, compact rows): lane b of the chain's wavefront factors block b (KNewtonFactor: LU of
+// D_b, D_b^-1 c_b, D_b^-1 dc/du_b, C_b, s_b, same operation order), the Woodbury core is summed over the lanes and solved
+// redundantly by every lane, lane b forms its block's multipliers and its share of the u-columns, lane 0 applies them to
+// the iterate (k_solve_chain_wave<.., 0, 0>), and lane b applies its multipliers to its interval frames (KMuF<RM, X, 0>).
+// What the three kernels passed through HBM (tpad, Ew, Cb, sb) stays in registers; results are bitwise theirs.
+// Three launches of 9-21 us each become one: sym_blk + solve_chain 0.45 -> see DESIGN.md.
+template <class M, int RM>
+__global__ void __launch_bounds__(64) k_newton_fsm_wave(Sys sy, Slots sl, Work w, int prev, int qsel) {
+  constexpr int U = M::U, X = M::X;
+  static_assert(RM <= 8, "one block per lane: the RM x RM matrix lives in registers");
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x;
+  if (c >= sy.B) return;
+  if (!newton_select(w, c, prev, qsel)) return;
+  const int sp = sl.cur[c] ^ prev;
+  const bool has = lane < sy.K;
+  const size_t cb = (size_t)c * sy.Kmax + (has ? lane : 0);
+  double D[RM * RM], JuL[RM * U], cp[RM];
+  unsigned long long eb = 0ULL;
+#pragma unroll
+  for (int i = 0; i < RM * RM; ++i) D[i] = has ? w.Dw[cb * RM * RM + i] : ((i / RM == i % RM) ? 1.0 : 0.0);
+#pragma unroll
+  for (int i = 0; i < RM * U; ++i) JuL[i] = has ? w.JuL[cb * RM * U + i] : 0.0;
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+    cp[i] = has ? w.cpad[cb * RM + i] : 0.0;
+    const unsigned long long vb = absbits(cp[i]);  // |c|_inf of the iterate (before the solve overwrites cp)
+    eb = vb > eb ? vb : eb;
+  }
+  {
+    int piv[RM];
+    lu_factor<RM>(D, piv);
+    lu_solve<RM, 1>(D, piv, cp);
+    lu_solve<RM, U>(D, piv, JuL);
+  }
+  const double* jur = pick(sl.JuP, sp) + cb * RM * U;
+  double ju[RM * U];
+#pragma unroll
+  for (int i = 0; i < RM * U; ++i) ju[i] = has ? jur[i] : 0.0;
+  double sacc[U], Cm[U * U];
+#pragma unroll
+  for (int a = 0; a < U; ++a) {
+    double t2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < RM; ++i) t2 += ju[i * U + a] * cp[i];
+    sacc[a] = has ? t2 : 0.0;
+#pragma unroll
+    for (int d = 0; d < U; ++d) {
+      double t = 0.0;
+#pragma unroll
+      for (int i = 0; i < RM; ++i) t += ju[i * U + a] * JuL[i * U + d];
+      Cm[a * U + d] = has ? t : 0.0;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < U; ++a) {
+    double v = sacc[a];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    sacc[a] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < U * U; ++i) {
+    double v = Cm[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    Cm[i] = v + (sy.m0 ? sy.m0[i] : ((i / U == i % U) ? 1.0 : 0.0));  // + M_0 (:794-798)
+  }
+  {
+    int piv[U];
+    lu_factor<U>(Cm, piv);
+    lu_solve<U, 1>(Cm, piv, sacc);
+  }
+  double lam[RM], du[U];
+#pragma unroll
+  for (int a = 0; a < U; ++a) du[a] = 0.0;
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+    double l = cp[i];
+#pragma unroll
+    for (int a = 0; a < U; ++a) l -= JuL[i * U + a] * sacc[a];
+    lam[i] = l;
+    if (has) w.lampad[cb * RM + i] = l;
+#pragma unroll
+    for (int a = 0; a < U; ++a) du[a] += ju[i * U + a] * l;
+  }
+#pragma unroll
+  for (int a = 0; a < U; ++a) {
+    double v = has ? du[a] : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    du[a] = v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long v = __shfl_xor(eb, o, 64);
+    eb = v > eb ? v : eb;
+  }
+  if (lane == 0) {
+    double* q = (qsel ? w.qb : pick(sl.q, sp ^ 1)) + (size_t)c * sy.Q;
+    unsigned long long nb = 0ULL;
+#pragma unroll
+    for (int a = 0; a < U; ++a) {
+      const double dq = metric_inv_u(sy, du, a);  // delta_q = metric.inv @ delta_mu (:1033-1041, :1105-1113)
+      q[a] -= dq;
+      const unsigned long long vb = absbits(dq);
+      nb = vb > nb ? vb : nb;
+    }
+    w.err[c] = bitsd(eb);
+    w.ndq[c] = nb;
+  }
+  if (has && w.muF) {  // mu_F[m] = sum_i lambda_i LF[m][i] of the previous point's interval frames
+    const BlockDesc bd = sy.blk[lane];
+    const double* lfb = pick(sl.LF, sp) + cb * sy.NOBS * RM * X;
+    double* mo = w.muF + cb * sy.NOBS * X;
+    for (int m = 0; m < sy.NOBS; ++m) {
+#pragma unroll
+      for (int a = 0; a < X; ++a) {
+        double t = 0.0;
+        if (m < bd.nobs) {
+#pragma unroll
+          for (int i = 0; i < RM; ++i)
+            if (i < bd.nrows) t += lam[i] * lfb[(m * RM + i) * X + a];
+        }
+        mo[m * X + a] = t;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // KNewtonFactor for 16-row blocks with the ROWS of the block over 16 lanes (four blocks per wavefront) instead of one
 // lane per block: a 16 x 16 matrix does not fit one lane's registers (the functor lives in scratch memory: 230 us per
 // launch on the SIR single-block layout, 17 launches per leapfrog step).  LU with partial pivoting in LAPACK getrf
@@ -3157,7 +3289,8 @@ __global__ void __launch_bounds__(64) k_newton_factor_wave(Sys sy, Slots sl, Wor
   const bool live = tid < sy.B * sy.K;
   const int tc = live ? tid : 0;
   const int c = tc / sy.K, b = tc - c * sy.K;
-  const bool act = live && w.nw[c] == 1;
+  int qsel_unused = 0;
+  const bool act = newton_select(w, c, prev, qsel_unused) && live;
   const int sp = sl.cur[c] ^ prev;
   const size_t cb = (size_t)c * sy.Kmax + b;
   double a[NC];
@@ -3416,6 +3549,18 @@ __global__ void __launch_bounds__(64) k_xobs_par(Sys sy, Slots sl, double* xobs_
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Is chain c part of this scan launch, and which iterate does it integrate?  use_nw 0: chains with work.ok; 1: chains of
+// the Newton loop (work.nw == 1); 3: the asynchronous engine's merged scan -- forward-retraction chains (work.nw: iterate
+// = the proposal slot's q) and reverse-retraction chains (work.nw2: iterate = work.qb) in one launch.
+__device__ inline bool scan_select(const Work& w, int c, int use_nw, int& which, int& qsel) {
+  if (use_nw == 3) {
+    int prev = 0;
+    if (!newton_select(w, c, prev, qsel)) return false;
+    which = prev ^ 1;
+    return true;
+  }
+  return use_nw ? w.nw[c] == 1 : w.ok[c] != 0;
+}
 template <class M, int RM, bool STORE>
 __global__ void __launch_bounds__(STORE ? 128 : 64)
     k_fwd_scan(Sys sy, Slots sl, Work w, int which, int qsel, int use_nw, int store_traj) {
@@ -3450,7 +3595,8 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
     int L = 0;
     if (t < n) {
       const int c = t / sy.K;
-      if (use_nw ? w.nw[c] == 1 : w.ok[c] != 0) L = sy.blk[t - c * sy.K].nsteps;
+      int wh_ = which, qs_ = qsel;
+      if (scan_select(w, c, use_nw, wh_, qs_)) L = sy.blk[t - c * sy.K].nsteps;
     }
     maxL = L;
 #pragma unroll
@@ -3473,9 +3619,10 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
       rp[i] = w.trajw, rL[i] = 0, lo_[i] = r * RSD + 2 * ch;  // (a global pointer: no generic-address stores)
       if (t < n) {
         const int c = t / sy.K, b = t - c * sy.K;
-        if (use_nw ? w.nw[c] == 1 : w.ok[c] != 0) {
+        int wh_ = which, qs_ = qsel;
+        if (scan_select(w, c, use_nw, wh_, qs_)) {
           const BlockDesc bd = sy.blk[b];
-          const int s = sl.cur[c] ^ which;
+          const int s = sl.cur[c] ^ wh_;
           rp[i] = (store_traj == 2 ? w.trajw : pick(sl.traj, s)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X + 2 * ch;
           rL[i] = bd.nsteps;
         }
@@ -3512,7 +3659,7 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
   const int tc = tid < n ? tid : n - 1;  // lanes past the end shadow the last block (valid addresses, no output)
   const int c = tc / sy.K, b = tc - c * sy.K;
   const BlockDesc bd = sy.blk[b];
-  const bool act = tid < n && (use_nw ? w.nw[c] == 1 : w.ok[c] != 0);
+  const bool act = scan_select(w, c, use_nw, which, qsel) && tid < n;  // (merged scan: which / qsel are the chain's own)
   const int L = act ? bd.nsteps : 0;
   const int s = sl.cur[c] ^ which;
   const double* q = (qsel ? w.qb : pick(sl.q, s)) + (size_t)c * sy.Q;
@@ -3648,14 +3795,35 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
 #ifndef CHMC_PAR_MAXS_LOOP
 #define CHMC_PAR_MAXS_LOOP 12
 #endif
-  const int MAXS = (use_nw && sy.K == 1) ? CHMC_PAR_MAXS_LOOP : 12;
+  // Asynchronous engine (use_nw == 3): a scan that has not settled after CHMC_PAR_MAXS_ASYNC sweeps is neither parked nor
+  // integrated sequentially: its start states are kept in the trajectory buffer, the chain's mask becomes 2 (no Newton
+  // iteration this round) and the next round's launch goes on sweeping from there -- nobody waits for it.
+#ifndef CHMC_PAR_MAXS_ASYNC
+#define CHMC_PAR_MAXS_ASYNC 6
+#endif
+  // (One block per chain only: with several blocks per chain the chain's mask would be shared by wavefronts that settle
+  // and wavefronts that do not; those layouts fall back to the sequential recursion inside the launch, as outside a loop.)
+  const bool async = use_nw == 3;
+  const bool apend = async && sy.K == 1;
+  const int MAXS = apend ? CHMC_PAR_MAXS_ASYNC : (!async && use_nw && sy.K == 1) ? CHMC_PAR_MAXS_LOOP : 12;
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x;
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (use_nw ? w.nw[c] == 0 : !w.ok[c]) return;
-  if (use_nw && w.nw[c] != 1) {
+  int* amask = nullptr;  // async: the mask entry of this chain's retraction
+  if (async) {
+    const int f = w.nw[c], r = w.nw2[c];
+    if (r == 1 || r == 2) {
+      amask = w.nw2 + c, which = 0, qsel = 1;
+    } else if (f == 1 || f == 2) {
+      amask = w.nw + c, which = 1, qsel = 0;
+    } else {
+      return;
+    }
+    gsel = (*amask == 2 || w.iters[c] > 0) ? 1 : 2;  // own previous sweeps / previous iterate; first iteration: the state's trajectory
+  } else if (use_nw ? w.nw[c] == 0 : !w.ok[c]) return;
+  if (!async && use_nw && w.nw[c] != 1) {
     // (K = 1) the scan of this chain's current iterate was handed to the side stream CHMC_REJOIN rounds ago, and the host has
     // made this launch wait for that piece of side-stream work: the chain re-joins the loop with its result (its iterate
     // has not changed meanwhile).  Flags of later rounds may be changing under our eyes and are not looked at.
@@ -3795,7 +3963,22 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
     converged = __ballot(unsettled) == 0ULL;
     if (converged && lane == 0 && w.nfallback) atomicAdd(w.nfallback + 1 + (sweep < 14 ? sweep : 14) + 16 * (gsel - 1), 1);
   }
-  if (!converged && use_nw && sy.K == 1) {
+  if (apend) {
+    if (!converged) {
+      // keep the junction states for the next round's sweeps (the guess is then this buffer: gsel 1)
+      if (lane > 0 && have) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) traj[(size_t)s0 * X + a] = Ul[a];
+      }
+      if (lane == 0) {
+        *amask = 2;
+        if (w.nfallback) atomicAdd(w.nfallback + 15, 1);
+      }
+      return;
+    }
+    if (lane == 0) *amask = 1;
+  }
+  if (!converged && !async && use_nw && sy.K == 1) {
     // Inside a Newton loop with one block per chain the sequential recursion is not done here, where it would hold up the
     // whole launch (and every kernel behind it) for one lost chain: the chain is parked (nw = 16 + round % 4), the side
     // stream integrates it (KFwd with that use_nw) while the loop's next two rounds run for the others, and it re-joins

@@ -55,7 +55,8 @@ class DynamicTransition:
                  total_chains=None, device=None, do_extra_subtree_checks=True):
         import torch
         self.torch = torch
-        self.ctx, self.step_size, self.seed = ctx, float(step_size), seed
+        self.ctx, self.seed = ctx, seed
+        self.step_size = step_size  # a number, or one step size per chain [B] (per-chain warm-up adaptation)
         self.max_tree_depth, self.max_delta_h = int(max_tree_depth), float(max_delta_h)
         self.solver = dict(newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10, max_iters=50,
                            reverse_check_tol=2e-8) if solver is None else solver
@@ -180,22 +181,28 @@ class DynamicTransition:
         ctx.restore_device(self.prop_q.data_ptr(), self.p.data_ptr(), np.ones(B, dtype=np.int32), False)
         n_step = st["n_step"].astype(np.int64)
         return dict(accept_stat=st["sum_acc"] / np.maximum(n_step, 1), n_step=n_step, depth=depth_reached, moved=moved,
-                    diverged=st["diverged"] != 0, integrator_error=st["failed"] != 0)
+                    diverged=st["diverged"] != 0, integrator_error=st["failed"] != 0, h0_finite=np.isfinite(h0))
 
 
 def sample_dynamic_chmc(ctx, n_iter, step_size, seed, n_adapt=0, chain_offset=0, total_chains=None, n_head=6,
                         trace_dir=None, trace_func=None, callback=None, **kw):
     """Momentum refresh -> dynamic transition -> partition switch, `n_iter` times for all chains of `ctx`, with
-    dual-averaging step-size adaptation on the tree's accept statistic (combined over all ranks) during warm-up:
-    the reference's sampling loop (scripts/utils.py:292-306, 338-365), batched."""
+    dual-averaging step-size adaptation on the tree's accept statistic during warm-up: the reference's sampling loop
+    (scripts/utils.py:292-306, 338-365), batched.  As in Mici every chain adapts its own step size during warm-up (the
+    integrator takes a step size per chain); the main phase runs with the average of the chains' adapted step sizes,
+    taken over the chains of all ranks."""
     import time
-    from .sampling import DualAveragingStepSize, _mean_over_all_chains
+    from .sampling import PerChainDualAveragingStepSize, _mean_over_all_chains
     tr = DynamicTransition(ctx, step_size, seed, chain_offset=chain_offset, total_chains=total_chains, **kw)
-    adapter = DualAveragingStepSize(step_size) if n_adapt > 0 else None
     B = ctx.B
+    adapter = PerChainDualAveragingStepSize(step_size, B) if n_adapt > 0 else None
     heads = np.empty((n_iter, B, n_head))
     acc_hist, eps_hist, nstep_hist = np.empty(n_iter), np.empty(n_iter), np.empty(n_iter)
     err_hist = np.empty(n_iter)
+    # per chain, main phase (after warm-up): transitions that moved the chain / did not, trees ended by an integrator error,
+    # by a divergence, trees with no leaf at all (first step failed), non-finite root Hamiltonian; leaves and accept-stat sums
+    outcome = np.zeros((B, 6), dtype=np.int64)
+    per_chain = dict(n_step=np.zeros(B), accept=np.zeros(B), err=np.zeros(B))
     writer, t0, c0 = None, time.perf_counter(), ctx.counters()
     if trace_func is None:
         def trace_func(head, ham):
@@ -212,22 +219,34 @@ def sample_dynamic_chmc(ctx, n_iter, step_size, seed, n_adapt=0, chain_offset=0,
                 writer = TraceWriter(trace_dir, B, n_iter, {k: v.shape[1:] for k, v in vals.items()})
             writer.write(it, vals)
         acc = _mean_over_all_chains(st["accept_stat"].sum(), B)
-        acc_hist[it], eps_hist[it] = acc, tr.step_size
+        acc_hist[it], eps_hist[it] = acc, float(np.mean(tr.step_size))
         nstep_hist[it], err_hist[it] = st["n_step"].mean(), st["integrator_error"].mean()
+        if it >= n_adapt:
+            outcome[:, 0] += st["moved"]
+            outcome[:, 1] += ~st["moved"]
+            outcome[:, 2] += st["integrator_error"]
+            outcome[:, 3] += st["diverged"]
+            outcome[:, 4] += st["n_step"] == 0
+            outcome[:, 5] += ~st["h0_finite"]
+            per_chain["n_step"] += st["n_step"]
+            per_chain["accept"] += st["accept_stat"]
+            per_chain["err"] += st["integrator_error"] | st["diverged"]
         if adapter is not None and it < n_adapt:
-            tr.step_size = adapter.update(acc)
+            tr.step_size = adapter.update(st["accept_stat"])  # [B]: every chain its own step size during warm-up
             if it == n_adapt - 1:
-                tr.step_size = adapter.final()
+                tr.step_size = _mean_over_all_chains(adapter.final().sum(), B)
         if callback is not None:
-            callback(it, heads[it], acc, tr.step_size, st)
+            callback(it, heads[it], acc, float(np.mean(tr.step_size)), st)
+    n_main = max(n_iter - n_adapt, 1)
     out = dict(heads=heads, accept_stat=acc_hist, step_size=eps_hist, n_step=nstep_hist, integrator_error=err_hist,
-               final_step_size=tr.step_size)
+               final_step_size=float(np.mean(tr.step_size)), chain_outcomes_dynamic=outcome,
+               per_chain={k: v / n_main for k, v in per_chain.items()})
     if writer is not None:
         from .traces import save_summary
         writer.flush()
         c1 = ctx.counters()
         main = {k: np.asarray(v)[:, n_adapt:] for k, v in writer.arrays().items()}
-        out["summary"] = save_summary(trace_dir, main, None, time.perf_counter() - t0, tr.step_size,
+        out["summary"] = save_summary(trace_dir, main, None, time.perf_counter() - t0, float(np.mean(tr.step_size)),
                                       {k: c1[k] - c0[k] for k in c1 if k != "_"})
         import os
         out["trace_files"] = {k: os.path.join(trace_dir, f"trace_{k}.npy") for k in writer.arrays()}

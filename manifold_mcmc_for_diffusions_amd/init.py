@@ -81,9 +81,100 @@ def fhn_initial_states_device(ctx, model, y_seq, seed=20200710, chain_offset=0, 
     return rngs
 
 
+def _torch_device(ctx):
+    try:
+        import torch
+    except ImportError:
+        return None
+    if ctx.L.chmc_backend() != b"hip:gfx950" or not torch.cuda.is_available():
+        return None
+    return torch.device("cuda", ctx.device)
+
+
+def init_objective_and_grad_device(ctx, u_v_dev_ptr, grad_dev_ptr):
+    """init_objective of the reference's finder (sde/mici_extensions.py:1706-1737) and its gradient for every chain, on
+    device buffers: 1/2 sum_t r_t^2 + T log sigma + 1/2 |u_v|^2 with r_t = (y_t - obs_func(x_t)) / sigma.  For a fixed
+    observation noise this is the unconstrained comparator's target (:82-205), which the library evaluates with one
+    forward scan and ONE adjoint sweep per chain (chmc_neg_log_dens_and_grad_device): no Jacobian blocks, no Gram
+    factors, no grad-log-det.  Returns the values [B] (host); the gradient is written to grad_dev [B, U + NV]."""
+    return ctx.neg_log_dens_and_grad_device(u_v_dev_ptr, grad_dev_ptr, use_gaussian_splitting=False)
+
+
+def _adam_on_device(ctx, rng, adam_step_size, max_iters, max_init_tries, threshold, slow_progress_ratio, check_iter,
+                    max_num_tries, log):
+    """The finder with (u_v, m, v) and the gradient resident in HBM: per Adam iteration ONE library call (scan + adjoint
+    sweep) and B-sized read-backs; the [B, Q] arrays never cross PCIe.  Same restart rules as the host loop below."""
+    import torch
+    dev = _torch_device(ctx)
+    B, Q, T = ctx.B, ctx.Q, ctx.T
+    nuv = Q - T
+    sigma = float(ctx.sigma)
+    u_v = torch.from_numpy(rng.standard_normal((B, nuv))).to(dev)
+    m, v, g = torch.zeros_like(u_v), torch.zeros_like(u_v), torch.empty_like(u_v)
+    t_adam = np.zeros(B)
+    done = np.zeros(B, dtype=bool)
+    tries = np.ones(B, dtype=np.int64)
+    prev = np.full(B, np.inf)
+    it_in_try = np.zeros(B, dtype=np.int64)
+    b1, b2, eps = 0.9, 0.999, 1e-8                         # jax.example_libraries.optimizers.adam defaults
+    col = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev).reshape(B, 1)  # noqa: E731
+    for _ in range(max_iters * max_num_tries):
+        torch.cuda.synchronize(dev)                        # (the library enqueues on its own stream)
+        val = init_objective_and_grad_device(ctx, u_v.data_ptr(), g.data_ptr())
+        sq = torch.linalg.vecdot(u_v, u_v)
+        gfin = torch.isfinite(g.sum(1))                    # (a non-finite entry makes the row sum non-finite)
+        sq, gfin = sq.cpu().numpy(), gfin.cpu().numpy()
+        msq = 2.0 * (val - T * np.log(sigma) - 0.5 * sq) / T   # mean squared residual
+        newly = ~done & np.isfinite(msq) & (msq < threshold)
+        done |= newly
+        if done.all():
+            break
+        stalled = (it_in_try % check_iter == 0) & (it_in_try > 0) & (it_in_try < max_iters // 2) & (
+            msq / prev > slow_progress_ratio)
+        restart = ~done & (~np.isfinite(msq) | ~gfin | stalled | (it_in_try >= max_iters))
+        upd = (it_in_try % check_iter == 0) & ~restart
+        prev = np.where(upd, msq, prev)
+        if restart.any():
+            if (tries[restart] >= max_num_tries * max_init_tries).any():
+                raise RuntimeError(f"Did not find valid state in {max_num_tries} tries.")
+            idx = torch.from_numpy(np.flatnonzero(restart)).to(dev)
+            u_v[idx] = torch.from_numpy(rng.standard_normal((int(restart.sum()), nuv))).to(dev)
+            m[idx], v[idx] = 0.0, 0.0
+            t_adam[restart], it_in_try[restart], prev[restart] = 0.0, 0, np.inf
+            tries[restart] += 1
+        step = ~done & ~restart
+        t_adam[step] += 1
+        # Adam moments in place for every chain (a finished chain's moments are never used again, a restarted chain's were
+        # zeroed above and its non-finite gradient is dropped); only the parameter update is masked
+        torch.nan_to_num_(g, nan=0.0, posinf=0.0, neginf=0.0)
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        tt = np.maximum(t_adam, 1.0)
+        upd = torch.sqrt(v * col(1.0 / (1 - b2 ** tt))).add_(eps)
+        torch.div(m, upd, out=upd)
+        u_v.sub_(upd.mul_(col(np.where(step, adam_step_size / (1 - b1 ** tt), 0.0))))
+        it_in_try[step] += 1
+        if log is not None and int(it_in_try.max()) % check_iter == 0:
+            log(f"  adam (device): {int(done.sum())} of {B} chains below the threshold, median mean r^2 {np.median(msq):.3g}")
+    else:
+        raise RuntimeError("Did not find valid states within the iteration budget.")
+    # n := residuals puts the point on the manifold (:1767-1775): one state evaluation at [u_v, 0] gives obs_func(x_t) - y_t
+    q = np.concatenate([u_v.cpu().numpy(), np.zeros((B, T))], 1)
+    xo0 = np.zeros((B, T, ctx.X))
+    ctx.set_state(q, None, xo0, 0)
+    res = -ctx.constr() / sigma
+    assert (np.mean(res ** 2, 1) < threshold * (1 + 1e-9)).all()
+    q[:, nuv:] = res
+    ctx.set_state(q, None, xo0, 0)
+    ctx.update_x_obs_seq()
+    xo = ctx.get_state(want_p=False)[2]
+    ctx.set_state(q, None, xo, 0)
+    return q, xo, tries
+
+
 def find_initial_states_by_gradient_descent_noisy_system(ctx, rng, adam_step_size=2e-2, max_iters=1000, max_init_tries=100,
                                                          threshold=1.0, slow_progress_ratio=0.8, check_iter=100,
-                                                         max_num_tries=10, log=None):
+                                                         max_num_tries=10, log=None, device_resident=None):
     """find_initial_state_by_gradient_descent_noisy_system (sde/mici_extensions.py:1679-1801), for every chain of `ctx`
     at once (the SIR script's initialisation, scripts/sir_model_chmc_experiment.py:103-109).
 
@@ -95,12 +186,21 @@ def find_initial_states_by_gradient_descent_noisy_system(ctx, rng, adam_step_siz
     library: `ctx` must hold the whole observation sequence in ONE sub-sequence (num_obs_per_subseq >= num_obs, i.e.
     K = 1, the SIR configuration), where the constraint function at n = 0 is obs_func(x_t) - y_t for the full scan and
     J^T lambda is its exact adjoint.  Chains restart from a fresh draw when Adam diverges or stalls, as in the reference.
-    Leaves the found states set on `ctx` (zero momentum) and returns (q [B, Q], x_obs_seq [B, T, X], tries [B])."""
+    Leaves the found states set on `ctx` (zero momentum) and returns (q [B, Q], x_obs_seq [B, T, X], tries [B]).
+
+    device_resident (None: when possible): with a fixed observation noise the iteration runs with (u_v, m, v) resident in
+    HBM and the objective / gradient from the library's scan + single adjoint sweep (`_adam_on_device`); the host loop
+    below (full state evaluation per iteration through the per-operator entry points) remains for sigma = generate_σ_y(u)."""
     if not ctx.noisy or ctx.num_blocks != 1 or ctx.num_partition != 1:
         raise ValueError("needs a noisy-observation context with a single sub-sequence (num_obs_per_subseq >= num_obs)")
     B, Q, T = ctx.B, ctx.Q, ctx.T
     nuv = Q - T
     var_sigma = getattr(ctx, "variable_sigma", False)
+    if not var_sigma and device_resident is not False and _torch_device(ctx) is not None:
+        return _adam_on_device(ctx, rng, adam_step_size, max_iters, max_init_tries, threshold, slow_progress_ratio, check_iter,
+                               max_num_tries, log)
+    if device_resident is True:
+        raise ValueError("the device-resident finder needs a fixed observation noise and a CUDA-capable torch")
     iσ = ctx.U - 1                                         # index of log sigma in u (variable observation noise)
     xo0 = np.zeros((B, T, ctx.X))
 

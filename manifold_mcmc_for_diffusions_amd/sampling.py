@@ -34,6 +34,37 @@ class DualAveragingStepSize:
         return float(np.exp(self.log_bar))
 
 
+class PerChainDualAveragingStepSize:
+    """The same adapter with one state per chain, as Mici runs it: every chain adapts ITS OWN step size on its own accept
+    statistic during warm-up (mici DualAveragingStepSizeAdapter keeps one adapter state per chain), and the step size of
+    the main phase is the average of the chains' smoothed step sizes (Mici's `finalize` with several chains, as recalled:
+    SURVEY.md Appendix D marks the adapter defaults `medium`).  A chain that starts where the shared step size is far too
+    long for its retraction (every first step an integrator error, accept statistic 0) thereby shortens its own steps
+    until it moves, instead of staying put for the whole run while dragging a shared step size down."""
+
+    def __init__(self, step_size, num_chains, target=0.8, gamma=0.05, t0=10.0, kappa=0.75):
+        self.mu = np.full(num_chains, np.log(10 * step_size))
+        self.target, self.gamma, self.t0, self.kappa = target, gamma, t0, kappa
+        self.h_bar = np.zeros(num_chains)
+        self.log_bar = np.full(num_chains, np.log(step_size))
+        self.t = 0
+        self.step_size = np.full(num_chains, float(step_size))
+
+    def update(self, accept_stat):
+        self.t += 1
+        eta = 1.0 / (self.t + self.t0)
+        self.h_bar = (1 - eta) * self.h_bar + eta * (self.target - np.asarray(accept_stat, dtype=np.float64))
+        log_eps = self.mu - np.sqrt(self.t) / self.gamma * self.h_bar
+        w = self.t ** (-self.kappa)
+        self.log_bar = w * log_eps + (1 - w) * self.log_bar
+        self.step_size = np.exp(log_eps)
+        return self.step_size
+
+    def final(self):
+        """Smoothed step size of every chain [B]; the caller averages over the chains of all ranks."""
+        return np.exp(self.log_bar)
+
+
 def _mean_over_all_chains(local_sum, local_count):
     """Mean of a per-chain statistic over the chains of every rank (one tiny all-reduce; SURVEY.md 8f #3: warm-up
     adaptation combines the chains of all GPUs so that every rank integrates with the same step size)."""
