@@ -139,6 +139,27 @@ int chmc_tree_step(chmc_ctx* ctx, const double* dt, int n_inner_step, int newton
                    int store_slot, int check_lo, int n_check, int* n_running);
 int chmc_tree_get(chmc_ctx* ctx, int* alive, int* run, int* n_step, int* failed, int* diverged, double* sub_logw,
                   double* sum_acc);
+/* The per-doubling logic of the same transition on the device (mici MultinomialDynamicIntegrationTransition.sample: the
+ * loop over tree depths around _build_tree), so that a doubling costs two calls with an 8-byte read-back each instead of
+ * per-chain host logic on [B][Q] vectors.  The tree vectors stay the caller's device buffers [B][Q].
+ *   chmc_tree_doubling_begin  for every live chain: direction fwd = u_dir[c] < 0.5; if the context's chain state sits on
+ *                             the other tree edge, the edge (neg or pos q, p) is copied into the state and its caches
+ *                             are re-evaluated; a new sub-tree begins (chmc_tree_subtree), sub_sum = 0.
+ *                             *n_alive = chains whose tree can still grow (0: the transition is over).
+ *   (2^depth chmc_tree_step calls with dt = +-step_size by the same comparison)
+ *   chmc_tree_doubling_end    for every chain whose sub-tree completed (run != 0): biased progressive sampling, the
+ *                             sub-tree's proposal replaces the tree's if u_accept[c] < min(1, exp(sub_logw - logw));
+ *                             logw = logaddexp(logw, sub_logw); sum_mom += sub_sum; the chain's current state becomes
+ *                             the tree's edge on the side of the doubling; then the no-U-turn criterion on the whole tree,
+ *                             dh_dmom(neg edge) . sum_mom < 0 or dh_dmom(pos edge) . sum_mom < 0 -> alive = 0 (sums in a
+ *                             fixed order).  *n_alive as above.
+ *   chmc_tree_get_doubling    per chain: whether the proposal moved, doublings completed, log weight of the tree. */
+int chmc_tree_doubling_begin(chmc_ctx* ctx, const double* u_dir, const void* neg_q_dev, const void* neg_p_dev,
+                             const void* pos_q_dev, const void* pos_p_dev, void* sub_sum_dev, int* n_alive);
+int chmc_tree_doubling_end(chmc_ctx* ctx, const double* u_accept, int depth, void* prop_q_dev, const void* sub_prop_q_dev,
+                           void* sum_mom_dev, const void* sub_sum_dev, void* neg_q_dev, void* neg_p_dev, void* pos_q_dev,
+                           void* pos_p_dev, int* n_alive);
+int chmc_tree_get_doubling(chmc_ctx* ctx, int* moved, int* depth, double* logw);
 int chmc_set_momentum(chmc_ctx* ctx, const double* p);
 int chmc_get_state_device(chmc_ctx* ctx, void* q_dev, void* p_dev);  /* device-to-device copies */
 int chmc_set_momentum_device(chmc_ctx* ctx, const void* p_dev);

@@ -47,6 +47,10 @@ SYMBOLS = [
                                  dp, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                  C.c_int, C.c_int, ip]),
     ("chmc_tree_get", C.c_int, [C.c_void_p, ip, ip, ip, ip, ip, dp, dp]),
+    ("chmc_tree_doubling_begin", C.c_int, [C.c_void_p, dp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, ip]),
+    ("chmc_tree_doubling_end", C.c_int, [C.c_void_p, dp, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, ip]),
+    ("chmc_tree_get_doubling", C.c_int, [C.c_void_p, ip, ip, dp]),
     ("chmc_set_momentum", C.c_int, [C.c_void_p, dp]),
     ("chmc_get_state_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("chmc_set_momentum_device", C.c_int, [C.c_void_p, C.c_void_p]),

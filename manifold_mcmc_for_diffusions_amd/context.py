@@ -161,6 +161,34 @@ class ChmcContext:
                                    iptr(o["diverged"]), ptr(o["sub_logw"]), ptr(o["sum_acc"])), "chmc_tree_get")
         return o
 
+    def tree_doubling_begin(self, u_dir, neg_q_ptr, neg_p_ptr, pos_q_ptr, pos_p_ptr, sub_sum_ptr):
+        """Direction, edge switch (with cache re-evaluation) and sub-tree start of one doubling, on the device; returns the
+        number of chains whose tree can still grow."""
+        u = as_c(np.asarray(u_dir, dtype=np.float64))
+        n = C.c_int(0)
+        check(self.L.chmc_tree_doubling_begin(self.h, ptr(u), C.c_void_p(neg_q_ptr), C.c_void_p(neg_p_ptr), C.c_void_p(pos_q_ptr),
+                                              C.c_void_p(pos_p_ptr), C.c_void_p(sub_sum_ptr), C.byref(n)),
+              "chmc_tree_doubling_begin")
+        return n.value
+
+    def tree_doubling_end(self, u_accept, depth, prop_q_ptr, sub_prop_q_ptr, sum_mom_ptr, sub_sum_ptr, neg_q_ptr, neg_p_ptr,
+                          pos_q_ptr, pos_p_ptr):
+        """Biased progressive sampling, momentum sum, new tree edge and whole-tree no-U-turn criterion of one doubling, on
+        the device; returns the number of chains whose tree can still grow."""
+        u = as_c(np.asarray(u_accept, dtype=np.float64))
+        n = C.c_int(0)
+        check(self.L.chmc_tree_doubling_end(self.h, ptr(u), int(depth), C.c_void_p(prop_q_ptr), C.c_void_p(sub_prop_q_ptr),
+                                            C.c_void_p(sum_mom_ptr), C.c_void_p(sub_sum_ptr), C.c_void_p(neg_q_ptr),
+                                            C.c_void_p(neg_p_ptr), C.c_void_p(pos_q_ptr), C.c_void_p(pos_p_ptr), C.byref(n)),
+              "chmc_tree_doubling_end")
+        return n.value
+
+    def tree_get_doubling(self):
+        moved, depth = np.zeros(self.B, dtype=np.int32), np.zeros(self.B, dtype=np.int32)
+        logw = np.zeros(self.B)
+        check(self.L.chmc_tree_get_doubling(self.h, iptr(moved), iptr(depth), ptr(logw)), "chmc_tree_get_doubling")
+        return dict(moved=moved != 0, depth=depth.astype(np.int64), logw=logw)
+
     def set_momentum(self, p):
         p = self._bq(p, "p")
         check(self.L.chmc_set_momentum(self.h, ptr(p)), "chmc_set_momentum")

@@ -116,7 +116,7 @@ static void streams_join() {
   }
   use_stream(-1);
 }
-static const bool g_no_stagger = getenv("CHMC_NO_STAGGER") != nullptr;  // experiments: halves in phase
+static const bool g_no_stagger = false;
 static void stagger_wait() {  // before a forward scan of the current half: the other half's latest scan must be done
   if (g_cur_half < 0 || g_no_stagger) return;
   const int o = g_cur_half ^ 1;
@@ -310,7 +310,11 @@ static void launch_rows(F f, int ncol, int B, int cls = 0) {
 }
 // row-sum launch: as the row launch, with `nacc` per-item accumulators that are summed over the workgroup (wave
 // shuffles, then LDS) and written as one partial per (chain, workgroup): partial [B][gridDim.x][nacc].  No atomics:
-// the caller adds the partials of a chain in a fixed order, so the sums are reproducible.
+// the caller adds the partials of a chain in a fixed order, so the sums are reproducible.  A work item visits
+// CHMC_ROWSUM_PAIRS column pairs (stride 256 pairs: coalesced), so that the cross-lane reduction of up to 60 accumulators
+// is paid once per 4 096 columns: with one pair per work item the reduction, not the memory traffic, set the time
+// (KTreeLeaf at configs[1]: 1.2 ms per launch, 157 partials per chain for the single-thread second stage).
+#define CHMC_ROWSUM_PAIRS 8
 template <class F>
 __global__ void __launch_bounds__(256) k_rowsum(F f, int ncol, int nacc, double* partial) {
   const int c = blockIdx.y;
@@ -318,8 +322,10 @@ __global__ void __launch_bounds__(256) k_rowsum(F f, int ncol, int nacc, double*
   double acc[CHMC_ROWSUM_MAX];
 #pragma unroll
   for (int a = 0; a < CHMC_ROWSUM_MAX; ++a) acc[a] = 0.0;
-  const int col = 2 * (blockIdx.x * 256 + threadIdx.x);
-  if (col < ncol) f(c, col, acc);
+  for (int k = 0; k < CHMC_ROWSUM_PAIRS; ++k) {
+    const int col = 2 * ((blockIdx.x * CHMC_ROWSUM_PAIRS + k) * 256 + threadIdx.x);
+    if (col < ncol) f(c, col, acc);
+  }
   __shared__ double sm[4][CHMC_ROWSUM_MAX];
 #pragma unroll
   for (int a = 0; a < CHMC_ROWSUM_MAX; ++a) {
@@ -335,7 +341,7 @@ __global__ void __launch_bounds__(256) k_rowsum(F f, int ncol, int nacc, double*
     partial[((size_t)c * gridDim.x + blockIdx.x) * nacc + threadIdx.x] =
         (sm[0][threadIdx.x] + sm[1][threadIdx.x]) + (sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
-static int rowsum_groups(int ncol) { return ((ncol + 1) / 2 + 255) / 256; }
+static int rowsum_groups(int ncol) { return ((ncol + 1) / 2 + 256 * CHMC_ROWSUM_PAIRS - 1) / (256 * CHMC_ROWSUM_PAIRS); }
 template <class F>
 static void launch_rowsum(F f, int ncol, int B, int nacc, double* partial, int cls = 0) {
   if (ncol <= 0 || B <= 0) return;
@@ -394,9 +400,8 @@ static void launch_wave(K kern, long nwaves, int cls, Args... args) {
     note(hipEventRecord(r.a, g_stream));
   }
   // one wavefront per workgroup: a SIMD takes the next (chain, block) as soon as its wavefront retires instead of
-  // waiting for the other three of a 256-thread workgroup (reverse sweep -3 %); CHMC_WAVES_PER_BLOCK overrides
-  static const int wpb_env = getenv("CHMC_WAVES_PER_BLOCK") ? atoi(getenv("CHMC_WAVES_PER_BLOCK")) : 1;
-  static const int wpb = wpb_env >= 1 && wpb_env <= 4 ? wpb_env : 1;
+  // waiting for the other three of a 256-thread workgroup (reverse sweep -3 %)
+  const int wpb = 1;
   hipLaunchKernelGGL(kern, dim3((unsigned)((nwaves + wpb - 1) / wpb)), dim3(64 * wpb), 0, g_stream, args...);
   note(hipGetLastError());
   if (prof) {

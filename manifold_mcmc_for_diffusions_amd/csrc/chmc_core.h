@@ -2485,6 +2485,12 @@ struct TreeState {
                                         // the leaves' acceptance probabilities, this leaf's uniform draw
   int *alive, *run, *take, *n_step, *failed, *diverged;  // [B]
   int* n_running;                                        // [1]
+  // per-doubling state (chmc_tree_doubling_begin / _end): log weight of the whole tree, direction of the current
+  // doubling, which tree edge the context's chain state sits on, whether the proposal has moved, doublings completed,
+  // chains whose current sub-tree completed / whose proposal moves to it / whose state has to be brought to the other edge
+  double *logw, *u2;
+  int *fwd, *at_pos, *at_neg, *moved, *depth, *done, *acc, *need;
+  int* counts;  // [2] chains alive, chains that need an edge switch
 };
 CHMC_HD inline double log_add_exp(double a, double b) {  // log(exp(a) + exp(b)), the formula of numpy.logaddexp
   if (a == b) return a + 0.6931471805599453;             // (also covers -inf, -inf)
@@ -2503,6 +2509,107 @@ struct KTreeBegin {
     t.run[c] = 0, t.take[c] = 0, t.n_step[c] = 0, t.failed[c] = 0, t.diverged[c] = 0;
     t.sum_acc[c] = 0.0;
     t.sub_logw[c] = -__builtin_huge_val();
+    t.logw[c] = -h, t.at_pos[c] = 1, t.at_neg[c] = 1, t.moved[c] = 0, t.depth[c] = 0, t.done[c] = 0, t.acc[c] = 0, t.need[c] = 0;
+  }
+};
+// ---- the per-doubling logic of the transition on the device (mici _build_tree's callers: direction draw, biased
+// progressive sampling between the old tree and the new sub-tree, whole-tree no-U-turn criterion; dynamic.py held these
+// on the host in round 2)
+struct KTreeDoubleBegin {  // direction of this doubling, edge switch needed?, new sub-tree (KTreeSubBegin)
+  TreeState t;
+  CHMC_HD void operator()(int c) const {
+    t.run[c] = t.alive[c];
+    t.sub_logw[c] = -__builtin_huge_val();
+    t.done[c] = 0, t.acc[c] = 0;
+    int need = 0;
+    if (t.alive[c]) {
+      const int fwd = t.u2[c] < 0.5 ? 1 : 0;
+      need = fwd ? !t.at_pos[c] : !t.at_neg[c];
+      t.fwd[c] = fwd, t.at_pos[c] = fwd, t.at_neg[c] = !fwd;
+      atomic_add_i32(t.counts, 1);
+      if (need) atomic_add_i32(t.counts + 1, 1);
+    }
+    t.need[c] = need;
+  }
+};
+struct KTreeRestoreEdge {  // chain state <- the tree edge the doubling extends from, for the chains that are on the other one
+  Sys sy;
+  Slots sl;
+  TreeState t;
+  const double *neg_q, *neg_p, *pos_q, *pos_p;
+  CHMC_HD void operator()(int tid) const {
+    const int c = tid / sy.Q;
+    if (!t.need[c]) return;
+    const int s = sl.cur[c];
+    pick(sl.q, s)[tid] = (t.fwd[c] ? pos_q : neg_q)[tid];
+    pick(sl.p, s)[tid] = (t.fwd[c] ? pos_p : neg_p)[tid];
+  }
+};
+struct KTreeDoubleDecide {  // after the sub-tree's leaves: biased progressive sampling (old tree vs new sub-tree)
+  TreeState t;
+  int depth;
+  CHMC_HD void operator()(int c) const {
+    const int done = t.run[c] != 0;  // the sub-tree completed without terminating
+    t.done[c] = done, t.acc[c] = 0;
+    if (!done) return;
+    const double d = t.sub_logw[c] - t.logw[c];
+    const int acc = t.u2[c] < exp(d < 0.0 ? d : 0.0) ? 1 : 0;
+    t.acc[c] = acc;
+    if (acc) t.moved[c] = 1;
+    t.logw[c] = log_add_exp(t.logw[c], t.sub_logw[c]);
+    t.depth[c] = depth + 1;
+  }
+};
+// one pass over the state of the chains whose sub-tree completed: proposal, momentum sum, the tree's new edge, and the two
+// sides of the whole-tree criterion dh_dmom(edge) . sum of momenta (row-sum launch: acc[0] negative edge, acc[1] positive)
+struct KTreeDoubleRows {
+  Sys sy;
+  Slots sl;
+  TreeState t;
+  double *prop_q, *sum_mom, *neg_q, *neg_p, *pos_q, *pos_p;
+  const double *sub_prop_q, *sub_sum;
+  CHMC_HD bool active(int c) const { return t.done[c] != 0; }
+  CHMC_HD double2_ vel(const double* base, size_t cq, int col, double2_ p) const {
+    if (sy.m0 && col < sy.U) {
+      p.x = metric_inv_u(sy, base + cq, col);
+      if (col + 1 < sy.U) p.y = metric_inv_u(sy, base + cq, col + 1);
+    }
+    return p;
+  }
+  CHMC_HD void operator()(int c, int col, double* acc) const {
+    const int s = sl.cur[c], fwd = t.fwd[c];
+    const size_t cq = (size_t)c * sy.Q, i = cq + col;
+    const bool two = col + 1 < sy.Q, wide = two && !(sy.Q & 1);
+    const double2_ q = ldv2(pick(sl.q, s) + i, wide, two), p = ldv2(pick(sl.p, s) + i, wide, two);
+    if (t.acc[c]) stv2(prop_q + i, ldv2(sub_prop_q + i, wide, two), wide, two);
+    double2_ S = ldv2(sum_mom + i, wide, two);
+    const double2_ ss = ldv2(sub_sum + i, wide, two);
+    S.x += ss.x, S.y += ss.y;
+    stv2(sum_mom + i, S, wide, two);
+    // the state after the sub-tree's last leaf is the tree's new edge on the side the doubling went; the other edge
+    // is the stored one (its u-part is read through the block metric: the stored buffer of the OTHER side is not written here)
+    const double* nbase = fwd ? neg_p : pick(sl.p, s);
+    const double* pbase = fwd ? pick(sl.p, s) : pos_p;
+    const double2_ pn = fwd ? ldv2(neg_p + i, wide, two) : p;
+    const double2_ pp = fwd ? p : ldv2(pos_p + i, wide, two);
+    stv2((fwd ? pos_q : neg_q) + i, q, wide, two);
+    stv2((fwd ? pos_p : neg_p) + i, p, wide, two);
+    const double2_ vn = vel(nbase, cq, col, pn), vp = vel(pbase, cq, col, pp);
+    acc[0] += vn.x * S.x + (two ? vn.y * S.y : 0.0);
+    acc[1] += vp.x * S.x + (two ? vp.y * S.y : 0.0);
+  }
+};
+struct KTreeDoubleFinish {  // whole-tree no-U-turn criterion (riemannian_no_u_turn_criterion) and the count of live chains
+  TreeState t;
+  const double* partial;  // [B][nwg][2]
+  int nwg;
+  CHMC_HD void operator()(int c) const {
+    if (t.done[c]) {
+      double d0 = 0.0, d1 = 0.0;
+      for (int g = 0; g < nwg; ++g) d0 += partial[((size_t)c * nwg + g) * 2], d1 += partial[((size_t)c * nwg + g) * 2 + 1];
+      if (d0 < 0.0 || d1 < 0.0) t.alive[c] = 0;
+    }
+    if (t.alive[c]) atomic_add_i32(t.counts, 1);
   }
 };
 struct KTreeSubBegin {  // a new sub-tree: every live chain runs, empty multinomial weight

@@ -3778,7 +3778,10 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
 // (iii) the trajectory entries are stored by the segment recursions themselves.  Sweeps repeat until no junction moved
 // by more than 1e-13 (relative).  Segments started from a useless guess may overflow; that is harmless (the exact prefix
 // reaches them), and where the true recursion itself overflows the NaNs are the result.  A block that is still not
-// settled after MAXS sweeps is integrated sequentially by lane 0: same result (counted in work.nfallback).
+// settled after MAXS sweeps is integrated sequentially by lane 0 (counted in work.nfallback).  Because the sweeps stop
+// at 1e-13 relative -- not at bitwise-still junctions -- the result equals the sequential recursion to about 1e-13, NOT bit
+// for bit; whether this kernel or the sequential scan runs depends on the batch (chmc_create: chains x blocks <= 1024), so
+// a chain's bits depend on the scan its shard selects (CHMC_PAR_SCAN fixes the choice; tests compare the two scans).
 // gsel: guess trajectory: 1 = the destination buffer itself (previous iterate), 2 = the state's trajectory (slot cur),
 // 3 = work.trajw (the last iterate of the retraction that produced the point being evaluated).
 template <class M, int RM>

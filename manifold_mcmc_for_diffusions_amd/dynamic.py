@@ -12,12 +12,17 @@ applied from the span's first leaf to the first leaf of its right half (left hal
 the last leaf of its left half to the span's last leaf (right half's momenta plus that leaf's).
 Tree vectors (edges, proposal, momentum sums, checkpoints) live in torch tensors on the context's device -- plumbing
 around the integrator step, which does all the work -- and the library re-evaluates a chain's state caches when its
-tree switches edges (`chmc_restore_device`), one batched evaluation per doubling at most.  The per-chain decisions of
-a leaf are taken on the device (`chmc_tree_step`: one library call and one 4-byte read-back per leaf); the host keeps
-the per-doubling logic (direction, biased progressive sampling, whole-tree criterion).
+tree switches edges, one batched evaluation per doubling at most.  Every per-chain decision is taken on the device: those
+of a leaf in `chmc_tree_step` (one library call and one 4-byte read-back per leaf), those of a doubling -- direction, edge
+switch, biased progressive sampling, whole-tree criterion -- in `chmc_tree_doubling_begin / _end` (two calls and 16 bytes
+per doubling); the host draws the keyed uniforms and loops.
 
 All random choices come from `TreeUniforms`, keyed by (seed, transition, purpose, depth, leaf) and the global chain
-index, so results do not depend on how chains are sharded or on the order in which an implementation asks for them.
+index, so they do not depend on how chains are sharded or on the order in which an implementation asks for them.  The
+chains' arithmetic is sharding-independent bit for bit as long as every shard runs the same forward-scan kernel: the library
+picks the time-parallel scan for few long blocks (chains x blocks per GPU <= 1024 with blocks of >= 1024 steps: the SIR
+single-block layout, or fewer than 52 FitzHugh-Nagumo chains per GPU), and that scan reproduces the sequential recursion
+to 1e-13 relative, not bitwise (csrc/chmc_wave.h k_fwd_par); CHMC_PAR_SCAN=0 / 1 fixes the choice.
 """
 import numpy as np
 
@@ -104,83 +109,43 @@ class DynamicTransition:
         B = ctx.B
         un = TreeUniforms(self.seed, it, self.total, self.off, B)
         self._fetch()
-        # per-chain tree state lives in the library (chmc_tree_*): the decisions of a leaf -- integrator error,
-        # divergence, multinomial weight and proposal, no-U-turn termination of sub-tree spans -- are taken on the
-        # device; the host sees the number of chains still running after a leaf and the per-chain state after a sub-tree
+        # Per-chain tree state lives in the library (chmc_tree_*): the decisions of a leaf (integrator error, divergence,
+        # multinomial weight and proposal, no-U-turn termination of sub-tree spans: chmc_tree_step) and of a doubling
+        # (direction, edge switch with cache re-evaluation, biased progressive sampling, whole-tree criterion:
+        # chmc_tree_doubling_begin / _end) are taken on the device; the host draws the keyed uniforms, chooses the sign of
+        # the step by the same comparison, and reads back 4-8 bytes per call.
         h0 = ctx.tree_begin()
         for t in (self.neg_q, self.pos_q, self.prop_q):
             t.copy_(self.q)
         for t in (self.neg_p, self.pos_p, self.sum_mom):
             t.copy_(self.p)
-        logw = -h0.copy()
-        at_pos = np.ones(B, dtype=bool)          # which edge the context currently holds (both at depth 0)
-        at_neg = np.ones(B, dtype=bool)
-        alive = np.isfinite(h0)
-        moved = np.zeros(B, dtype=bool)
-        depth_reached = np.zeros(B, dtype=np.int64)
+        self._sync()  # the library works on its own stream
         ck_end = None if self.ck_end is None else self.ck_end.data_ptr()
-        st = None
+        edges = (self.neg_q.data_ptr(), self.neg_p.data_ptr(), self.pos_q.data_ptr(), self.pos_p.data_ptr())
         for d in range(self.max_tree_depth):
-            if not alive.any():
+            u_dir = un.get(un.DIRECTION, d)
+            if ctx.tree_doubling_begin(u_dir, *edges, self.sub_sum.data_ptr()) == 0:
                 break
-            fwd = un.get(un.DIRECTION, d) < 0.5
-            # bring the context to the edge each live chain extends from
-            need = alive & np.where(fwd, ~at_pos, ~at_neg)
-            if need.any():
-                src_q = torch.where(self._mask(fwd)[:, None], self.pos_q, self.neg_q)
-                src_p = torch.where(self._mask(fwd)[:, None], self.pos_p, self.neg_p)
-                self._sync()
-                ctx.restore_device(src_q.data_ptr(), src_p.data_ptr(), need.astype(np.int32), True)
-            at_pos = np.where(alive, fwd, at_pos)
-            at_neg = np.where(alive, ~fwd, at_neg)
-            dt = np.where(fwd, self.step_size, -self.step_size)
-            # ---- sub-tree of 2^d leaves
-            self.sub_sum.zero_()
-            self._sync()  # the library works on its own stream
-            ctx.tree_subtree()
+            dt = np.where(u_dir < 0.5, self.step_size, -np.asarray(self.step_size))
+            # ---- sub-tree of 2^d leaves: one call per leaf (integrator step + momentum sum, multinomial proposal,
+            # checkpoint of an even leaf, for an odd leaf the no-U-turn checks over every sub-tree span that ends there)
             for k in range(1 << d):
                 lo, hi = _ckpt_range(k)
                 even = k % 2 == 0
-                # one call per leaf: integrator step + (chmc_tree_step) momentum sum, multinomial proposal, checkpoint of
-                # an even leaf, and for an odd leaf the no-U-turn checks over every sub-tree span that ends here
                 n_run = ctx.tree_step(dt, un.get(un.LEAF, d, k), self.max_delta_h, self.sub_prop_q.data_ptr(),
                                       self.sub_sum.data_ptr(), self.ck_p.data_ptr(), self.ck_sum.data_ptr(), ck_end,
                                       hi if even else -1, lo, 0 if even else hi - lo + 1, **self.solver)
                 if n_run == 0:
                     break
-            st = ctx.tree_get()
-            alive = st["alive"] != 0
-            done = st["run"] != 0  # chains whose sub-tree completed without terminating
-            sub_logw = st["sub_logw"]
-            if not done.any():
-                continue
-            self._fetch()  # state after the sub-tree's last leaf: the tree's new edge
-            depth_reached = np.where(done, d + 1, depth_reached)
-            # biased progressive sampling between the old tree and the new sub-tree
-            acc = done & (un.get(un.ACCEPT, d) < np.exp(np.minimum(0.0, np.where(done, sub_logw - logw, -np.inf))))
-            moved |= acc
-            am, dm = self._mask(acc), self._mask(done)
-            self.prop_q.copy_(torch.where(am[:, None], self.sub_prop_q, self.prop_q))
-            logw = np.where(done, np.logaddexp(logw, np.where(done, sub_logw, -np.inf)), logw)
-            self.sum_mom.add_(torch.where(dm[:, None], self.sub_sum, torch.zeros_like(self.sub_sum)))
-            fm = self._mask(done & fwd)[:, None]
-            bm = self._mask(done & ~fwd)[:, None]
-            self.pos_q.copy_(torch.where(fm, self.q, self.pos_q))
-            self.pos_p.copy_(torch.where(fm, self.p, self.pos_p))
-            self.neg_q.copy_(torch.where(bm, self.q, self.neg_q))
-            self.neg_p.copy_(torch.where(bm, self.p, self.neg_p))
-            # no-U-turn criterion on the whole tree (riemannian_no_u_turn_criterion: dh_dmom(edge) . sum of momenta)
-            turn = ((self._dot(self.neg_p, self.sum_mom) < 0) | (self._dot(self.pos_p, self.sum_mom) < 0)).cpu().numpy()
-            if (done & turn).any():
-                alive = alive & ~(done & turn)
-                ctx.tree_set_alive(alive.astype(np.int32))
-        if st is None:
-            st = ctx.tree_get()
+            if ctx.tree_doubling_end(un.get(un.ACCEPT, d), d, self.prop_q.data_ptr(), self.sub_prop_q.data_ptr(),
+                                     self.sum_mom.data_ptr(), self.sub_sum.data_ptr(), *edges) == 0:
+                break
+        st = ctx.tree_get()
+        dbl = ctx.tree_get_doubling()
         # leave the selected positions on the context (every chain: the context may sit on a tree edge)
-        self._sync()
         ctx.restore_device(self.prop_q.data_ptr(), self.p.data_ptr(), np.ones(B, dtype=np.int32), False)
         n_step = st["n_step"].astype(np.int64)
-        return dict(accept_stat=st["sum_acc"] / np.maximum(n_step, 1), n_step=n_step, depth=depth_reached, moved=moved,
+        return dict(accept_stat=st["sum_acc"] / np.maximum(n_step, 1), n_step=n_step, depth=dbl["depth"], moved=dbl["moved"],
                     diverged=st["diverged"] != 0, integrator_error=st["failed"] != 0, h0_finite=np.isfinite(h0))
 
 

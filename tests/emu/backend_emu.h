@@ -45,7 +45,7 @@ static void launch_rows(F f, int ncol, int B, int cls = 0) {
     for (int col = 0; col < ncol; col += 2) f(c, col);
   }
 }
-static int rowsum_groups(int ncol) { return ((ncol + 1) / 2 + 255) / 256; }
+static int rowsum_groups(int ncol) { return ((ncol + 1) / 2 + 2047) / 2048; }  // 8 column pairs per work item x 256
 template <class F>
 static void launch_rowsum(F f, int ncol, int B, int nacc, double* partial, int cls = 0) {
   (void)cls;
@@ -55,7 +55,7 @@ static void launch_rowsum(F f, int ncol, int B, int nacc, double* partial, int c
     for (int g = 0; g < ng; ++g) {
       double acc[CHMC_ROWSUM_MAX];
       for (int a = 0; a < CHMC_ROWSUM_MAX; ++a) acc[a] = 0.0;
-      for (int col = g * 512; col < ncol && col < (g + 1) * 512; col += 2) f(c, col, acc);
+      for (int col = g * 4096; col < ncol && col < (g + 1) * 4096; col += 2) f(c, col, acc);
       for (int a = 0; a < nacc; ++a) partial[((size_t)c * ng + g) * nacc + a] = acc[a];
     }
   }

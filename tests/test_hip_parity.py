@@ -582,13 +582,13 @@ print("MFMA_LAUNCHES", d1["gram_mfma_launches"], d1["gram_mfma_launches"] - d0["
 def test_fp64_mfma_gram_kernel_boarding_school_sir():
     """BASELINE.json configs[4] names an fp64-MFMA J J^T Gram build.  The kernel (k_gram_rows_mfma,
     v_mfma_f64_16x16x4_f64 over the stored rows of 16-row blocks) is optional -- the vector-FMA kernel is faster on this
-    part -- so it is run here in a child process with CHMC_GRAM_MFMA=1 CHMC_COMPACT16=0 (the
+    part -- so it is run here in a child process with CHMC_GRAM_MFMA=1 (the
     stored-rows Newton sweep, the only path that forms a Gram block from rows): every per-op entry point (chol_D is the
     factor of the MFMA-built Gram) and one leapfrog step of the boarding-school SIR chains against the C oracle, and the
     library's own launch counters must show that the MFMA kernel, not the vector kernel, did the work."""
     import subprocess
     script = _MFMA_SCRIPT.format(root=ROOT, tests=os.path.join(ROOT, "tests"))
-    env = {**os.environ, "CHMC_GRAM_MFMA": "1", "CHMC_COMPACT16": "0"}
+    env = {**os.environ, "CHMC_GRAM_MFMA": "1"}
     r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("MFMA_LAUNCHES")][-1].split()
@@ -794,15 +794,15 @@ np.savez({out!r}, **out)
 
 @pytest.mark.parametrize("model,T,S,R,extra", [("fhn", 100, 400, 5, ""), ("sir", 14, 200, 14, ", obs_interval=0.25")])
 def test_compact_row_kernels_agree_with_the_stored_row_kernels_full_size(tmp_path, model, T, S, R, extra):
-    """Two kernel families for the same step at the full BASELINE sizes: the default path (compact rows PB / LF, lean
-    Newton / state / grad-log-det sweeps, two-phase sweep for 16-row blocks, time-parallel x_obs at the partition switch)
-    against the stored-rows kernels of round 1 (every switch off), each in its own process (the switches are read once).
+    """The library's two kernel families for the same step at the full BASELINE sizes: the default path (compact rows PB /
+    LF: two-phase Newton sweep + fused factor / solve kernel, lean state and grad-log-det sweeps, time-parallel x_obs at
+    the partition switch) against the stored-rows kernels of round 1 (CHMC_COMPACT_ROWS=0, the only family switch left),
+    each in its own process (the switch is read once).
     Two leapfrog steps per partition and a partition switch: positions, momenta, x_obs to 1e-9 relative, statuses and
     Newton iteration counts equal."""
     import subprocess
     outs = []
-    for name, env in (("compact", {}), ("stored", {"CHMC_COMPACT_ROWS": "0", "CHMC_XOBS_PAR": "0", "CHMC_NEWTON_LEAN": "0",
-                                                      "CHMC_STATE_LEAN": "0", "CHMC_GLD_LEAN": "0", "CHMC_TWO_PHASE8": "0"})):
+    for name, env in (("compact", {}), ("stored", {"CHMC_COMPACT_ROWS": "0"})):
         out = str(tmp_path / f"{name}.npz")
         script = _PATH_SCRIPT.format(root=ROOT, tests=os.path.join(ROOT, "tests"), model=model, T=T, S=S, R=R, extra=extra, out=out)
         r = subprocess.run([sys.executable, "-c", script], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
@@ -815,3 +815,37 @@ def test_compact_row_kernels_agree_with_the_stored_row_kernels_full_size(tmp_pat
         else:
             scale = max(np.abs(b[k]).max(), 1.0)
             assert np.abs(a[k] - b[k]).max() <= 1e-9 * scale, (k, np.abs(a[k] - b[k]).max(), scale)
+
+
+def test_time_parallel_scan_against_the_sequential_scan(monkeypatch):
+    """CHMC_PAR_SCAN (read at chmc_create): the SIR single-block layout with the time-parallel forward scan (multiple
+    shooting, parked chains on the side stream; the automatic choice for few long blocks) against the same steps with the
+    sequential lane-per-block scan: statuses and Newton iteration counts equal, positions to 1e-9, over 64 distinct chains x
+    6 steps with two chains whose retraction diverges."""
+    B = 64
+    case = _distinct_on_manifold_chains("sir", 14, 200, 14, B, seed=74, obs_interval=0.25)
+    rng = np.random.default_rng(12)
+    p = rng.standard_normal(case["q"].shape)
+    dts = np.where(np.arange(B) % 2 == 0, 1.0, -1.0) * (0.01 + 0.03 * rng.random(B))
+    dts[[9, 33]] = 5.0
+    out = []
+    for par in ("1", "0"):
+        monkeypatch.setenv("CHMC_PAR_SCAN", par)
+        ctx = make_ctx(case)
+        ctx.set_state(case["q"], p, case["x_obs"], 0)
+        ctx.project_onto_cotangent_space()
+        res = [ctx.leapfrog_step(dts, max_iters=15) for _ in range(6)]
+        q1, p1, _, _ = ctx.get_state()
+        launches = int(ctx.diagnostics()["par_scan"][1:48].sum())
+        out.append((res, q1, p1, launches))
+        ctx.close()
+    (ra, qa, pa, na), (rb, qb, pb, nb) = out
+    assert na > 0 and nb == 0  # the time-parallel kernel ran in the first context only
+    differ = 0
+    for x, y in zip(ra, rb):
+        np.testing.assert_array_equal(x["status"], y["status"])
+        differ += int((x["iters_fwd"] != y["iters_fwd"]).sum() + (x["iters_bwd"] != y["iters_bwd"]).sum())
+    assert differ <= 2  # (a count may differ on the edge of a tolerance: the scans agree to 1e-13, not bitwise)
+    assert (ra[0]["status"][[9, 33]] > 0).all()
+    if differ == 0:
+        assert np.abs(qa - qb).max() <= 1e-9 * max(1.0, np.abs(qb).max())

@@ -49,8 +49,12 @@ def test_posterior_and_sampler_statistics_with_the_dynamic_transition(tmp_path):
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import fhn_notebook_posterior as nb
     rows, res, n_moving = nb.run(64, 450, 150, 0, out_dir=str(tmp_path / "run"), verbose=False, transition="dynamic")
-    assert n_moving >= 45
-    assert 0.7 < res["accept_stat"][150:].mean() < 0.92
+    # every chain adapts its own step size during warm-up (as Mici's adapter does), so no start is left behind ...
+    assert n_moving >= 60
+    # ... and the main phase runs with the MEAN of the chains' adapted step sizes (Mici's finalize): with 64 prior draws as
+    # starts, a few of them in stiff regions with tiny adapted steps, that mean is shorter than what a healthy chain would
+    # pick, hence an accept statistic above the 0.8 target (the notebook's two chains: 0.83)
+    assert 0.7 < res["accept_stat"][150:].mean() < 0.97
     assert 15.0 < res["n_step"][150:].mean() < 45.0
     assert res["integrator_error"][150:].mean() < 0.4
     for r in rows:

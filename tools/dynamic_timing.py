@@ -40,10 +40,15 @@ def timed(obj, name):
     setattr(obj, name, g)
 
 
-for nm in ("tree_begin", "tree_subtree", "tree_step", "tree_get", "tree_set_alive", "get_state_device", "restore_device", "sample_momentum",
-           "switch_partition"):
+for nm in ("tree_begin", "tree_doubling_begin", "tree_step", "tree_doubling_end", "tree_get", "tree_get_doubling",
+           "get_state_device", "restore_device", "sample_momentum", "switch_partition"):
     timed(ctx, nm)
 tr = DynamicTransition(ctx, 0.09, seed=3, max_tree_depth=5)
+import ctypes as C  # noqa: E402
+from manifold_mcmc_for_diffusions_amd import _lib  # noqa: E402
+L = _lib.lib()
+if os.environ.get("CHMC_TIMING_CLASSES"):
+    L.chmc_profile_enable(1)
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 steps = 0
@@ -61,3 +66,12 @@ for k in acc:
     print(f"  {k:18s} {acc[k] / steps * 1e3:7.3f} ms per leaf  ({cnt[k]} calls, {acc[k] / cnt[k] * 1e3:.3f} ms each)")
     tot += acc[k]
 print(f"  {'torch / numpy rest':18s} {(el - tot) / steps * 1e3:7.3f} ms per leaf")
+
+if os.environ.get("CHMC_TIMING_CLASSES"):
+    ms = np.zeros(10)
+    nl = np.zeros(10, dtype=np.int64)
+    L.chmc_profile_get(ms.ctypes.data_as(_lib.dp), nl.ctypes.data_as(C.POINTER(C.c_longlong)))
+    L.chmc_profile_enable(0)
+    print("kernel classes, ms per leaf (launches per leaf): " + ", ".join(
+        f"{k} {ms[i] / steps:.3f} ({nl[i] / steps:.1f})" for i, k in enumerate(_lib.KERNEL_CLASSES) if nl[i]))
+    print(f"sum of classes {ms.sum() / steps:.3f} ms per leaf")
