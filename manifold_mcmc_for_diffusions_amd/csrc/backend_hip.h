@@ -128,34 +128,6 @@ static void stagger_record() {
   note(hipEventRecord(g_stag_ev[h][g_stag_n[h] % kStagRing], g_stream));
   g_stag_n[h]++;
 }
-// ---- side stream of the Newton loop (deferred sequential scans of the time-parallel forward scan): the work enqueued
-// between side_begin() and side_end() runs on the second half-batch stream behind everything the main stream has queued
-// so far; side_wait() makes the main stream wait for the latest such piece
-// (pieces are numbered by `slot` 0 .. 3 so that the main stream can wait for the piece of two rounds ago while the
-// latest one is still running)
-static thread_local hipEvent_t g_side_fork = nullptr, g_side_done[4];
-static thread_local bool g_side_pending[4] = {false, false, false, false};
-static thread_local hipStream_t g_side_saved = nullptr;
-static void side_begin() {
-  if (!g_side_fork) {
-    note(hipEventCreateWithFlags(&g_side_fork, hipEventDisableTiming));
-    for (int i = 0; i < 4; ++i) note(hipEventCreateWithFlags(&g_side_done[i], hipEventDisableTiming));
-  }
-  note(hipEventRecord(g_side_fork, g_stream));
-  note(hipStreamWaitEvent(g_streams[2], g_side_fork, 0));
-  g_side_saved = g_stream;
-  g_stream = g_streams[2];
-}
-static void side_end(int slot) {
-  note(hipEventRecord(g_side_done[slot], g_stream));
-  g_stream = g_side_saved;
-  g_side_pending[slot] = true;
-}
-static void side_wait(int slot) {
-  if (!g_side_pending[slot]) return;
-  note(hipStreamWaitEvent(g_stream, g_side_done[slot], 0));
-  g_side_pending[slot] = false;
-}
 // ---- asynchronous trajectory engine (chmc_leapfrog_steps): (i) batches of state evaluations run on the auxiliary stream
 // behind everything the main stream has queued so far (aux_begin / aux_end, numbered by `slot`); the host asks with
 // aux_done() whether a batch has finished and only then makes the main stream depend on it (aux_join), so the main

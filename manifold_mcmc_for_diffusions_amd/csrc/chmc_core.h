@@ -102,13 +102,6 @@ struct Slots {
   int* cur;
 };
 
-// Rounds a chain whose forward scan was handed to the side stream sits out before it re-joins its Newton loop (k_fwd_par,
-// run_projection).  The sequential scan of a 2 800-step chain takes 0.9 ms; with the two-phase sweep a round of the SIR
-// single-block loop takes 0.25-0.3 ms, so two rounds made the main stream wait for the side stream almost every time.
-// At most 3: four generations of flags (round & 3) are in flight.
-#ifndef CHMC_REJOIN
-#define CHMC_REJOIN 3
-#endif
 struct Work {
   double* muF;      // [B][Kmax][NOBS][X]  sum_i lambda_i LF[m][i]: the multipliers applied to the interval frames
   double* muF2;     //                     the same for lampad2 (two-vector projection)
@@ -144,9 +137,8 @@ struct Work {
   double* dt;       // [B]
   double* part;     // [B][NPART] partial sums
   int* iters;       // [B]
-  int* nw;          // [B] Newton loop: 0 finished, 1 iterating; 16 + g / 32 + g: the forward scan of the current iterate
-                    //     was handed to the side stream in a round with (round & 3) == g and is pending / done -- the
-                    //     chain sits out the rounds until the loop picks it up again (k_fwd_par, K = 1)
+  int* nw;          // [B] Newton loop: 0 finished, 1 iterating, 2 the time-parallel forward scan of the current iterate has
+                    //     not settled yet: the chain sits this round out and its scan goes on in the next (k_fwd_par, K = 1)
   int* nw2;         // asynchronous engine (use_nw == 3 in the forward scans): the reverse-retraction mask next to the
                     //     forward-retraction mask in `nw`; one merged scan serves both groups, each chain with its own
                     //     (slot, iterate) selection.  Null outside the engine.
@@ -635,7 +627,7 @@ struct KFwd {
       int prev = 0;
       if (!newton_select(w, c, prev, qsel)) return;
       which = prev ^ 1;
-    } else if (use_nw ? w.nw[c] != use_nw : !w.ok[c]) return;  // (use_nw 16 + g: the deferred scans of the side stream)
+    } else if (use_nw ? w.nw[c] != 1 : !w.ok[c]) return;
     const int s = sl.cur[c] ^ which;
     const double* q = (qsel ? w.qb : pick(sl.q, s)) + (size_t)c * sy.Q;
     ChainConsts<M> cc;
@@ -647,7 +639,6 @@ struct KFwd {
     fwd_block<M, RM>(sy, bd, cc, q, sy.xobs + (size_t)c * sy.T * M::X, traj, cp);
     double* out = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
     for (int i = 0; i < RM; ++i) out[i] = cp[i];
-    if (use_nw >= 16) w.nw[c] = use_nw + 16;  // deferred scan done: the chain re-joins the loop two rounds on (K = 1)
   }
 };
 
@@ -1866,7 +1857,7 @@ struct KCheck {
   int max_iters, B;
   CHMC_HD void operator()(int c) const {
     if (!w.nw[c]) return;
-    if (w.nw[c] != 1) {  // its forward scan is still with the side stream: not this round's iteration, but not finished
+    if (w.nw[c] != 1) {  // its time-parallel forward scan has not settled: not this round's iteration, but not finished
       atomic_add_i32(w.n_active, 1);
       return;
     }

@@ -3280,8 +3280,11 @@ __global__ void __launch_bounds__(64) k_newton_fsm_wave(Sys sy, Slots sl, Work w
 // order (:745-752) on the augmented rows [D | c | dc/du]: pivot search and row exchange by 16-lane shuffles, the
 // elimination of a column is one FMA per lane and entry, the forward substitution rides along (same operation order as
 // lu_solve), the back substitution runs column by column.  Then E = D^-1 dc/du, t = D^-1 c, C_b and s_b as KNewtonFactor.
-template <class M, int RM>
-__global__ void __launch_bounds__(64) k_newton_factor_wave(Sys sy, Slots sl, Work w, int prev) {
+// FUSE (one block per chain, K = 1: the chain's Woodbury system is this block's): the 16 lanes go on to solve the core
+// system, form the multipliers, apply their u-columns to the iterate and apply them to the interval frames -- the work
+// of k_solve_chain_wave<.., 0, 0> and KMuF<16, X, 0>, two launches of a latency-bound round less.
+template <class M, int RM, bool FUSE = false>
+__global__ void __launch_bounds__(64) k_newton_factor_wave(Sys sy, Slots sl, Work w, int prev, int qsel) {
   static_assert(RM == 16, "rows over 16 lanes");
   constexpr int U = M::U, NC = RM + 1 + U;  // augmented row: D row | c | dc/du row
   const int lane = threadIdx.x & 63, r = lane & 15;
@@ -3289,14 +3292,14 @@ __global__ void __launch_bounds__(64) k_newton_factor_wave(Sys sy, Slots sl, Wor
   const bool live = tid < sy.B * sy.K;
   const int tc = live ? tid : 0;
   const int c = tc / sy.K, b = tc - c * sy.K;
-  int qsel_unused = 0;
-  const bool act = newton_select(w, c, prev, qsel_unused) && live;
+  const bool act = newton_select(w, c, prev, qsel) && live;
   const int sp = sl.cur[c] ^ prev;
   const size_t cb = (size_t)c * sy.Kmax + b;
   double a[NC];
 #pragma unroll
   for (int k = 0; k < RM; ++k) a[k] = act ? w.Dw[cb * RM * RM + r * RM + k] : (k == r ? 1.0 : 0.0);
   a[RM] = act ? w.cpad[cb * RM + r] : 0.0;
+  const double c0 = a[RM];  // the constraint value of this row (|c|_inf of the iterate, FUSE)
 #pragma unroll
   for (int d = 0; d < U; ++d) a[RM + 1 + d] = act ? w.JuL[cb * RM * U + r * U + d] : 0.0;
 #pragma unroll
@@ -3346,18 +3349,82 @@ __global__ void __launch_bounds__(64) k_newton_factor_wave(Sys sy, Slots sl, Wor
   double jur[U];
 #pragma unroll
   for (int d = 0; d < U; ++d) jur[d] = act ? pick(sl.JuP, sp)[cb * RM * U + r * U + d] : 0.0;
+  double sacc[U], Cm[U * U];
 #pragma unroll
   for (int aa = 0; aa < U; ++aa) {
     double v = jur[aa] * a[RM];
 #pragma unroll
     for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
-    if (act && r == 0) w.sb[cb * U + aa] = v;
+    if (!FUSE && act && r == 0) w.sb[cb * U + aa] = v;
+    sacc[aa] = v;
 #pragma unroll
     for (int d = 0; d < U; ++d) {
       double t = jur[aa] * a[RM + 1 + d];
 #pragma unroll
       for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 16);
-      if (act && r == 0) w.Cb[(cb * U + aa) * U + d] = t;
+      if (!FUSE && act && r == 0) w.Cb[(cb * U + aa) * U + d] = t;
+      Cm[aa * U + d] = t;
+    }
+  }
+  if constexpr (FUSE) {
+    // (every lane of the block holds s = s_b and C_b: the core system C = M_0 + C_b, y = C^-1 s, redundantly per lane)
+    constexpr int X = M::X;
+    __shared__ double lamS[4][RM];
+#pragma unroll
+    for (int i = 0; i < U * U; ++i) Cm[i] += sy.m0 ? sy.m0[i] : ((i / U == i % U) ? 1.0 : 0.0);
+    {
+      int piv[U];
+      lu_factor<U>(Cm, piv);
+      lu_solve<U, 1>(Cm, piv, sacc);
+    }
+    double l = a[RM];
+#pragma unroll
+    for (int d = 0; d < U; ++d) l -= a[RM + 1 + d] * sacc[d];
+    if (act) w.lampad[cb * RM + r] = l;
+    lamS[lane >> 4][r] = l;
+    double du[U];
+#pragma unroll
+    for (int aa = 0; aa < U; ++aa) {
+      double v = jur[aa] * l;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+      du[aa] = v;
+    }
+    unsigned long long eb = absbits(c0);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const unsigned long long v = __shfl_xor(eb, o, 16);
+      eb = v > eb ? v : eb;
+    }
+    if (act && r == 0) {
+      double* q = (qsel ? w.qb : pick(sl.q, sp ^ 1)) + (size_t)c * sy.Q;
+      unsigned long long nb = 0ULL;
+#pragma unroll
+      for (int aa = 0; aa < U; ++aa) {
+        const double dq = metric_inv_u(sy, du, aa);  // delta_q = metric.inv @ delta_mu (:1033-1041, :1105-1113)
+        q[aa] -= dq;
+        const unsigned long long vb = absbits(dq);
+        nb = vb > nb ? vb : nb;
+      }
+      w.err[c] = bitsd(eb);
+      w.ndq[c] = nb;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (act && w.muF) {  // mu_F[m] = sum_i lambda_i LF[m][i] of the previous point's interval frames (KMuF)
+      const BlockDesc bd = sy.blk[b];
+      const double* lfb = pick(sl.LF, sp) + cb * sy.NOBS * RM * X;
+      double* mo = w.muF + cb * sy.NOBS * X;
+      const double* ls = lamS[lane >> 4];
+      for (int e = r; e < sy.NOBS * X; e += 16) {
+        const int m = e / X, ax = e - m * X;
+        double t = 0.0;
+        if (m < bd.nobs) {
+          for (int i = 0; i < RM; ++i)
+            if (i < bd.nrows) t += ls[i] * lfb[(m * RM + i) * X + ax];
+        }
+        mo[e] = t;
+      }
     }
   }
 }
@@ -3553,10 +3620,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // the Newton loop (work.nw == 1); 3: the asynchronous engine's merged scan -- forward-retraction chains (work.nw: iterate
 // = the proposal slot's q) and reverse-retraction chains (work.nw2: iterate = work.qb) in one launch.
 __device__ inline bool scan_select(const Work& w, int c, int use_nw, int& which, int& qsel) {
-  if (use_nw == 3) {
-    int prev = 0;
-    if (!newton_select(w, c, prev, qsel)) return false;
-    which = prev ^ 1;
+  if (use_nw == 3) {  // (same selection as newton_select, chmc_core.h; which = prev ^ 1)
+    const bool rev = w.nw2[c] == 1;
+    if (!rev && w.nw[c] != 1) return false;
+    which = rev ? 0 : 1, qsel = rev ? 1 : 0;
     return true;
   }
   return use_nw ? w.nw[c] == 1 : w.ok[c] != 0;
@@ -3791,24 +3858,22 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
   // chain whose retraction is diverging (healthy blocks settle in 2-9 sweeps): it is handed to the sequential
   // recursion, which costs the same 0.9 ms as the remaining sweeps would
   constexpr int X = M::X, V = M::V;
-  // Inside a Newton loop with one block per chain an unsettled chain is parked for the side stream (below) and the whole
-  // round waits for the slowest wavefront of this launch: 99.8 % of the scans settle within 6 sweeps (tools/
-  // par_scan_stats.py).  (Stopping the loop's launches at 6 sweeps was measured slower, 19.6 -> 21.0 ms per step: every
-  // parked chain sits out CHMC_REJOIN rounds, which lengthens the loop by more than the shorter launches save.)
-#ifndef CHMC_PAR_MAXS_LOOP
-#define CHMC_PAR_MAXS_LOOP 12
+  // Inside a Newton loop (lock-step: use_nw == 1; asynchronous engine: use_nw == 3) with ONE block per chain a scan that has
+  // not settled after CHMC_PAR_MAXS_ROUND sweeps is neither integrated sequentially nor handed to another stream: its
+  // junction states are kept in the trajectory buffer, the chain's mask becomes 2 -- the round's other kernels and the
+  // convergence check skip it, it takes no iteration -- and the next round's launch goes on sweeping from there.  A launch
+  // therefore never lasts longer than CHMC_PAR_MAXS_ROUND sweeps (99.8 % of the scans settle within 6, tools/
+  // par_scan_stats.py), and nothing is handed to another stream: round 2's scheme (12 sweeps, then the chain parked for a
+  // 0.9 ms sequential scan on a side stream, re-joining three rounds later) cost boarding-school SIR at 256 chains
+  // 22.7 k against 26.3 k steps/s.
+  // (With several blocks per chain the chain's mask would be shared by wavefronts that settle and wavefronts that do not:
+  // those layouts keep 12 sweeps and the sequential recursion inside the launch, as outside a loop.)
+#ifndef CHMC_PAR_MAXS_ROUND
+#define CHMC_PAR_MAXS_ROUND 12  // measured at 256 boarding-school SIR chains: 4: 22.5 k, 6: 25.0 k, 8: 25.9 k, 10: 26.1 k, 12: 26.3 k, 16: 25.7 k steps/s
 #endif
-  // Asynchronous engine (use_nw == 3): a scan that has not settled after CHMC_PAR_MAXS_ASYNC sweeps is neither parked nor
-  // integrated sequentially: its start states are kept in the trajectory buffer, the chain's mask becomes 2 (no Newton
-  // iteration this round) and the next round's launch goes on sweeping from there -- nobody waits for it.
-#ifndef CHMC_PAR_MAXS_ASYNC
-#define CHMC_PAR_MAXS_ASYNC 6
-#endif
-  // (One block per chain only: with several blocks per chain the chain's mask would be shared by wavefronts that settle
-  // and wavefronts that do not; those layouts fall back to the sequential recursion inside the launch, as outside a loop.)
   const bool async = use_nw == 3;
-  const bool apend = async && sy.K == 1;
-  const int MAXS = apend ? CHMC_PAR_MAXS_ASYNC : (!async && use_nw && sy.K == 1) ? CHMC_PAR_MAXS_LOOP : 12;
+  const bool apend = (async || use_nw == 1) && sy.K == 1;
+  const int MAXS = apend ? CHMC_PAR_MAXS_ROUND : 12;
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x;
   if (wid >= sy.B * sy.K) return;
@@ -3825,16 +3890,17 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
       return;
     }
     gsel = (*amask == 2 || w.iters[c] > 0) ? 1 : 2;  // own previous sweeps / previous iterate; first iteration: the state's trajectory
-  } else if (use_nw ? w.nw[c] == 0 : !w.ok[c]) return;
-  if (!async && use_nw && w.nw[c] != 1) {
-    // (K = 1) the scan of this chain's current iterate was handed to the side stream CHMC_REJOIN rounds ago, and the host has
-    // made this launch wait for that piece of side-stream work: the chain re-joins the loop with its result (its iterate
-    // has not changed meanwhile).  Flags of later rounds may be changing under our eyes and are not looked at.
-    if (lane == 0 && w.nw[c] == 32 + ((round + 4 - CHMC_REJOIN) & 3)) w.nw[c] = 1;
+  } else if (use_nw) {
+    const int f = w.nw[c];
+    if (f != 1 && !(apend && f == 2)) return;
+    if (apend) {
+      amask = w.nw + c;
+      if (f == 2) gsel = 1;  // carry on from the junction states kept by the previous round's launch
+    }
+  } else if (!w.ok[c]) {
     return;
   }
-  // (Sending every later iterate of a chain that was parked once straight to the side stream was measured much slower,
-  // 19.6 -> 31 ms per step: most such chains settle again, and a parked iterate costs 0.9 ms plus CHMC_REJOIN rounds.)
+  (void)round;
   const BlockDesc bd = sy.blk[b];
   const int s_ = sl.cur[c] ^ which;
   const int S = sy.S, L = bd.nsteps;
@@ -3980,17 +4046,6 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
       return;
     }
     if (lane == 0) *amask = 1;
-  }
-  if (!converged && !async && use_nw && sy.K == 1) {
-    // Inside a Newton loop with one block per chain the sequential recursion is not done here, where it would hold up the
-    // whole launch (and every kernel behind it) for one lost chain: the chain is parked (nw = 16 + round % 4), the side
-    // stream integrates it (KFwd with that use_nw) while the loop's next two rounds run for the others, and it re-joins
-    // the loop two rounds later.  Its iteration count, status and result are those of the plain loop.
-    if (lane == 0) {
-      w.nw[c] = 16 + (round & 3);
-      if (w.nfallback) atomicAdd(w.nfallback + 15, 1);
-    }
-    return;
   }
   if (!converged && lane == 0) {  // sequential recursion (same arithmetic as fwd_block_impl)
     double x[X], xn[X];
