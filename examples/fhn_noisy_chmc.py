@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end example on an MI355X: posterior sampling for the FitzHugh-Nagumo model with noisy observations
 (the configuration of scripts/fhn_model_noisy_obs_chmc_experiment.py in the reference: T = 100 observations,
-R = 5, sigma_y = 0.1) with batched constrained HMC.   usage: fhn_noisy_chmc.py [chains] [S] [iters] [warm-up] [output dir] [static|dynamic|metric]
+R = 5, sigma_y = 0.1) with batched constrained HMC.   usage: fhn_noisy_chmc.py [chains] [S] [iters] [warm-up] [output dir] [static|dynamic|dynamic-shared|metric]
 `metric`: static trajectories with the block-diagonal metric adapter of the reference (sde/mici_extensions.py:1804-1931) on the
 four global parameters during the warm-up.
 With an output directory the traced variables of the reference's trace function (sigma, epsilon, gamma, beta, x_0,
@@ -21,7 +21,8 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 n_iter = int(sys.argv[3]) if len(sys.argv) > 3 else 150
 n_warm = int(sys.argv[4]) if len(sys.argv) > 4 else 50
 out_dir = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "-" else None
-dynamic = len(sys.argv) > 6 and sys.argv[6] == "dynamic"  # the reference's transition (no-U-turn trees) instead of 16 fixed steps
+dynamic = len(sys.argv) > 6 and sys.argv[6] in ("dynamic", "dynamic-shared")  # the reference's transition (no-U-turn trees) instead of 16 fixed steps
+shared_step = len(sys.argv) > 6 and sys.argv[6] == "dynamic-shared"        # one shared step size in the warm-up instead of one per chain
 adapt_metric = len(sys.argv) > 6 and sys.argv[6] == "metric"
 
 
@@ -38,6 +39,7 @@ t0 = time.time()
 if dynamic:
     from manifold_mcmc_for_diffusions_amd.dynamic import sample_dynamic_chmc  # noqa: E402
     res = sample_dynamic_chmc(wl.ctx, n_iter, 0.1, seed=wl.seed, n_adapt=n_warm, trace_dir=out_dir, trace_func=trace_func,
+                              per_chain_step_size=not shared_step,
                               callback=lambda it, h, a, e, st: (it % 10 == 0) and print(
                                   f"  iter {it:4d} accept {a:.2f} step {e:.3f} steps per tree {st['n_step'].mean():.1f} "
                                   f"z-median {np.median(em.fhn.generate_z(h[:, :4]), 0).round(3)}", flush=True))

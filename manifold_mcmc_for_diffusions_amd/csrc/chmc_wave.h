@@ -3142,6 +3142,88 @@ __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// KGldPrep for 16-row blocks with the block over 16 lanes (four blocks per wavefront): lane r solves for column r of
+// D_b^-1 against the Cholesky factor parked in LDS (the per-column recurrences of cho_solve, same operation order), forms
+// row r of W_u = E C^-1 and column r of (G^-1)_bb = D_b^-1 - W_u E^T.  The one-lane functor keeps three 16 x 16 matrices in
+// scratch memory: 206-247 us per launch on the SIR single-block layout.
+template <class M, int RM>
+__global__ void __launch_bounds__(64) k_gld_prep_wave(Sys sy, Slots sl, Work w, int which) {
+  static_assert(RM == 16, "rows over 16 lanes");
+  constexpr int Z = M::Z, U = M::U;
+  __shared__ double Ls[4][RM * RM], Es[4][RM * U], Ws[4][RM * U];
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  const int tid = blockIdx.x * 4 + g;
+  const bool live = tid < sy.B * sy.K;
+  const int tc = live ? tid : 0;
+  const int c = tc / sy.K, b = tc - c * sy.K;
+  const bool act = live && w.ok[c] != 0;
+  const int s = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int nrows = sy.blk[b].nrows;
+  double* L = Ls[g];
+  double e[U], wu[U];
+  {
+    const double* fd = pick(sl.facD, s) + cb * RM * RM + r * RM;
+#pragma unroll
+    for (int k = 0; k < RM; ++k) L[r * RM + k] = act ? fd[k] : (k == r ? 1.0 : 0.0);
+    const double* E = pick(sl.E, s) + cb * RM * U + r * U;
+    const double* Ci = pick(sl.Cinv, s) + (size_t)c * U * U;
+#pragma unroll
+    for (int a = 0; a < U; ++a) e[a] = act ? E[a] : 0.0;
+#pragma unroll
+    for (int d = 0; d < U; ++d) {
+      double t = 0.0;
+#pragma unroll
+      for (int a = 0; a < U; ++a) t += e[a] * (act ? Ci[a * U + d] : 0.0);
+      wu[d] = t;
+      Ws[g][r * U + d] = t;
+      Es[g][r * U + d] = e[d];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // column r of D^-1 = (L L^T)^-1: forward then backward substitution with right-hand side e_r
+  double x[RM];
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+    double t = i == r ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < RM; ++k)
+      if (k < i) t -= L[i * RM + k] * x[k];
+    x[i] = t / L[i * RM + i];
+  }
+#pragma unroll
+  for (int i = RM - 1; i >= 0; --i) {
+    double t = x[i];
+#pragma unroll
+    for (int k = 0; k < RM; ++k)
+      if (k > i) t -= L[k * RM + i] * x[k];
+    x[i] = t / L[i * RM + i];
+  }
+  if (!act) return;
+  // (G^-1)_bb[i][r] = D^-1[i][r] - sum_a W_u[i][a] E[r][a]; padded rows and columns are zero
+#pragma unroll
+  for (int i = 0; i < RM; ++i) {
+    double t = 0.0;
+#pragma unroll
+    for (int a = 0; a < U; ++a) t += Ws[g][i * U + a] * e[a];
+    const double v = (i >= nrows || r >= nrows) ? 0.0 : x[i] - t;
+    w.gMb[cb * RM * RM + i * RM + r] = v;
+  }
+  double Gz[Z * Z];
+  M::gz_jac(pick(sl.q, s) + (size_t)c * sy.Q, Gz);
+#pragma unroll
+  for (int d = 0; d < U; ++d) w.gWu[(cb * RM + r) * U + d] = wu[d];
+#pragma unroll
+  for (int mz = 0; mz < Z; ++mz) {
+    double t = 0.0;
+#pragma unroll
+    for (int d = 0; d < Z; ++d) t += Gz[mz * Z + d] * wu[d];
+    w.gzd[(cb * RM + r) * Z + mz] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Newton iteration, everything between the Gram blocks and the J^T lambda column pass in ONE launch (blocks of at most 8
 // rows, at most 64 blocks per chain, compact rows): lane b of the chain's wavefront factors block b (KNewtonFactor: LU of
 // D_b, D_b^-1 c_b, D_b^-1 dc/du_b, C_b, s_b, same operation order), the Woodbury core is summed over the lanes and solved

@@ -150,17 +150,22 @@ class DynamicTransition:
 
 
 def sample_dynamic_chmc(ctx, n_iter, step_size, seed, n_adapt=0, chain_offset=0, total_chains=None, n_head=6,
-                        trace_dir=None, trace_func=None, callback=None, **kw):
+                        trace_dir=None, trace_func=None, callback=None, per_chain_step_size=True, **kw):
     """Momentum refresh -> dynamic transition -> partition switch, `n_iter` times for all chains of `ctx`, with
     dual-averaging step-size adaptation on the tree's accept statistic during warm-up: the reference's sampling loop
     (scripts/utils.py:292-306, 338-365), batched.  As in Mici every chain adapts its own step size during warm-up (the
     integrator takes a step size per chain); the main phase runs with the average of the chains' adapted step sizes,
-    taken over the chains of all ranks."""
+    taken over the chains of all ranks.  per_chain_step_size=False: ONE step size adapted on the accept statistic
+    averaged over all chains (round 2's scheme): the batched trees of a doubling then all have the same number of leaves to
+    offer, which keeps the lock-step batch full during warm-up (the FitzHugh-Nagumo example: 30 k against 24 k leapfrog
+    steps/s end to end), but a chain that starts where that step size is far too long never moves."""
     import time
-    from .sampling import PerChainDualAveragingStepSize, _mean_over_all_chains
+    from .sampling import DualAveragingStepSize, PerChainDualAveragingStepSize, _mean_over_all_chains
     tr = DynamicTransition(ctx, step_size, seed, chain_offset=chain_offset, total_chains=total_chains, **kw)
     B = ctx.B
-    adapter = PerChainDualAveragingStepSize(step_size, B) if n_adapt > 0 else None
+    adapter = None
+    if n_adapt > 0:
+        adapter = PerChainDualAveragingStepSize(step_size, B) if per_chain_step_size else DualAveragingStepSize(step_size)
     heads = np.empty((n_iter, B, n_head))
     acc_hist, eps_hist, nstep_hist = np.empty(n_iter), np.empty(n_iter), np.empty(n_iter)
     err_hist = np.empty(n_iter)
@@ -197,9 +202,14 @@ def sample_dynamic_chmc(ctx, n_iter, step_size, seed, n_adapt=0, chain_offset=0,
             per_chain["accept"] += st["accept_stat"]
             per_chain["err"] += st["integrator_error"] | st["diverged"]
         if adapter is not None and it < n_adapt:
-            tr.step_size = adapter.update(st["accept_stat"])  # [B]: every chain its own step size during warm-up
-            if it == n_adapt - 1:
-                tr.step_size = _mean_over_all_chains(adapter.final().sum(), B)
+            if per_chain_step_size:
+                tr.step_size = adapter.update(st["accept_stat"])  # [B]: every chain its own step size during warm-up
+                if it == n_adapt - 1:
+                    tr.step_size = _mean_over_all_chains(adapter.final().sum(), B)
+            else:
+                tr.step_size = adapter.update(acc)
+                if it == n_adapt - 1:
+                    tr.step_size = adapter.final()
         if callback is not None:
             callback(it, heads[it], acc, float(np.mean(tr.step_size)), st)
     n_main = max(n_iter - n_adapt, 1)

@@ -31,6 +31,6 @@ cp $O/traffic.json $R/profiles/traffic.json
 python bench.py > $O/bench_fhn_noisy_with_traffic.json 2> $O/bench_fhn_noisy_with_traffic.err || tail -5 $O/bench_fhn_noisy_with_traffic.err
 python examples/fhn_notebook_posterior.py 64 700 200 24 > $O/notebook_posterior_64x700.log 2>&1; tail -12 $O/notebook_posterior_64x700.log
 python examples/fhn_noisy_chmc.py 256 400 120 40 $O/fhn_run > $O/example_fhn_sampler_256x400.log 2>&1; tail -4 $O/example_fhn_sampler_256x400.log
-python examples/fhn_noisy_chmc.py 256 400 60 25 - dynamic > $O/example_fhn_dynamic_256x400.log 2>&1; grep "leapfrog steps/s" $O/example_fhn_dynamic_256x400.log
+python examples/fhn_noisy_chmc.py 256 400 60 25 - dynamic > $O/example_fhn_dynamic_256x400.log 2>&1; grep "leapfrog steps/s" $O/example_fhn_dynamic_256x400.log; python examples/fhn_noisy_chmc.py 256 400 60 25 - dynamic-shared > $O/example_fhn_dynamic_shared_step_256x400.log 2>&1; grep "leapfrog steps/s" $O/example_fhn_dynamic_shared_step_256x400.log; python tools/adam_timing.py 1024 > $O/adam_init_1024.log 2>&1; tail -1 $O/adam_init_1024.log; python tools/adam_timing.py 256 > $O/adam_init_256.log 2>&1; tail -1 $O/adam_init_256.log; python tools/dynamic_timing.py > $O/dynamic_timing.log 2>&1; head -3 $O/dynamic_timing.log
 python examples/sir_boarding_school_chmc.py 256 300 100 16 > $O/example_sir_boarding_school_256.log 2>&1; tail -4 $O/example_sir_boarding_school_256.log
 rm -rf $O/fhn_run
