@@ -190,12 +190,12 @@ int chmc_switch_partition(chmc_ctx* ctx);
  * never writes the full rows of blocks with at most 8 rows.  The entry points below that return rows or multiply by them
  * rebuild the row-slot array first (one extra pass, only when called); results are the same to rounding.
  *
- * Environment switches (read when a context is created or at first use; for A/B measurements and debugging only):
- *   CHMC_COMPACT_ROWS=0   stored-rows passes everywhere          CHMC_STORE_ROWS=1  keep writing the full rows as well
- *   CHMC_COMPACT16=0      stored-rows Newton sweep for 16-row blocks    CHMC_GLD_COMPACT=0 / CHMC_GLD_LEAN=0  older grad-log-det sweeps
- *   CHMC_NEWTON_LEAN=0    one-wave-per-SIMD Newton sweep          CHMC_GRAM_MFMA=1   fp64-MFMA Gram kernel (16-row blocks)
- *   CHMC_TWO_PHASE8=0     one-kernel Newton sweep for blocks of at most 8 rows      CHMC_XOBS_PAR=0 / CHMC_STATE_LEAN=0  older x_obs / state sweeps
- *   CHMC_PAR_SCAN=0/1     time-parallel forward scan off / forced CHMC_HALVES=2      two overlapped half-batches per step */
+ * Environment switches (read when a context is created or at first use; each is exercised by a GPU test):
+ *   CHMC_COMPACT_ROWS=0   round 1's stored-rows kernel family everywhere (the A/B partner of the default)
+ *   CHMC_GRAM_MFMA=1      fp64-MFMA Gram kernel for 16-row blocks (on the stored-rows Newton sweep)
+ *   CHMC_PAR_SCAN=0/1     time-parallel forward scan off / forced      CHMC_NO_FWD_SCAN=1  generic functor instead of the
+ *   CHMC_HALVES=2         two overlapped half-batches per step           hand-scheduled forward scan
+ *   CHMC_ASYNC=1          asynchronous per-chain-phase engine behind chmc_leapfrog_steps (read at every call) */
 int chmc_constr(chmc_ctx* ctx, double* c);                                  /* :473-519, :1151-1155  [B][C] */
 /* :521-624, :1157-1161.  dc_du [B][C][U]; dc_dv [B][RM][NV] row-slot layout (slot i = row i of the block that
  * owns the column); dc/dn is sigma on observation rows (:601-608). */
