@@ -146,6 +146,8 @@ struct Work {
   int* status;      // [B]
   int* nstat;       // [B] status of last projection
   int* n_active;    // [1]
+  unsigned* ticket; // [B] workgroups of a column-max launch that have finished a chain (the last one runs the launch's
+                    //     per-chain epilogue: KUpdatePB's fused convergence check)
   const double* zeros;  // [256] zeros (stand-in source for loads of structurally zero Jacobian entries)
   int* nfallback;   // [1] blocks the time-parallel forward scan handed to its sequential fallback (diagnostic)
 };
@@ -1448,6 +1450,7 @@ CHMC_HD inline void stv2(double* p, double2_ v, bool wide, bool two) {
 }
 template <int RM, int TGT, int VEC>
 struct KUpdate {
+  static constexpr bool kFinish = false;
   Sys sy;
   Slots sl;
   Work w;
@@ -1625,12 +1628,40 @@ struct KMuF {
     if (TGT == 3) w.muF2[(cb * sy.NOBS + m) * X + a] = t2;
   }
 };
+struct CheckArgs {  // KCheck's arguments riding on the Newton update pass (do_check == 0: no fused check)
+  double ctol, ptol, dtol;
+  int max_iters, do_check;
+  int* iters_dst;  // the step's iteration counter of this retraction direction (KAddIters), or null
+};
 template <int RM, int X, int V, int TGT, int NS = 1>
 struct KUpdatePB {  // NS: consecutive steps per work item (2 when S is even: both lie in the same observation interval)
+  // TGT 0 with chk.do_check: the LAST workgroup to finish a chain's columns (ticket counter) runs KCheck for that chain --
+  // the lax.while_loop condition needs max |delta q|, which is complete exactly then -- and adds the finished loop's
+  // iteration count to the step's counter (KAddIters): two launches of every Newton round less.
+  static constexpr bool kFinish = TGT == 0;
   Sys sy;
   Slots sl;
   Work w;
   int which, qsel, psel;
+  CheckArgs chk;
+  CHMC_HD bool has_finish() const { return TGT == 0 && chk.do_check != 0; }
+  CHMC_HD unsigned* ticket(int c) const { return w.ticket + c; }
+  CHMC_HD void finish(int c, unsigned long long ndq_bits) const {
+    w.ticket[c] = 0u;
+    const int i = ++w.iters[c];
+    const double err = w.err[c], ndq = bitsd(ndq_bits);
+    const bool diverged = (err > chk.dtol) || (err != err);
+    const bool converged = (err < chk.ctol) && (ndq < chk.ptol);
+    if (i >= chk.max_iters || diverged || converged) {
+      w.nw[c] = 0;
+      const int st = converged ? 0 : (diverged ? 2 : 1);
+      w.nstat[c] = st;
+      if (st) w.ok[c] = 0, w.status[c] = st;
+      if (chk.iters_dst) chk.iters_dst[c] += i;
+    } else {
+      atomic_add_i32(w.n_active, 1);
+    }
+  }
   CHMC_HD bool active(int c) const {
     int p_ = 0, q_ = 0;
     return TGT == 0 ? newton_select(w, c, p_, q_) : w.ok[c] != 0;
@@ -1855,6 +1886,8 @@ struct KCheck {
   Work w;
   double ctol, ptol, dtol;
   int max_iters, B;
+  int* iters_dst;  // the step's iteration counter of this retraction direction, or null: a chain's count is added when ITS
+                   // loop ends, failed or not (KAddIters: "a chain that failed in this solve still reports its iterations")
   CHMC_HD void operator()(int c) const {
     if (!w.nw[c]) return;
     if (w.nw[c] != 1) {  // its time-parallel forward scan has not settled: not this round's iteration, but not finished
@@ -1870,6 +1903,7 @@ struct KCheck {
       int st = converged ? 0 : (diverged ? 2 : 1);
       w.nstat[c] = st;
       if (st) w.ok[c] = 0, w.status[c] = st;
+      if (iters_dst) iters_dst[c] += i;
     } else {
       atomic_add_i32(w.n_active, 1);
     }
@@ -2110,6 +2144,7 @@ struct KKickFlowPg {
 };
 // reverse check distance max |q_back - q_start| (mici maximum_norm); column-max kernel, two components per work item
 struct KRevDiff {
+  static constexpr bool kFinish = false;
   Sys sy;
   Slots sl;
   Work w;

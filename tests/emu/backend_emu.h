@@ -72,6 +72,9 @@ static void launch_colmax(F f, int ncol, int B, int cls = 0) {
     }
     unsigned long long* t = f.red(c);
     if (t && v > *t) *t = v;
+    if constexpr (F::kFinish) {
+      if (t && f.has_finish()) f.finish(c, *t);
+    }
   }
 }
 extern "C" int chmc_profile_enable(int) { return 0; }

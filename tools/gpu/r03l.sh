@@ -2,7 +2,7 @@ export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/r03l
 mkdir -p $O
-timeout -k 10 900 python -m pytest tests/test_hip_parity.py tests/test_async_engine.py -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc $?" >> $O/pytest.log
 tail -4 $O/pytest.log
 grep -q "pytest rc 0" $O/pytest.log || exit 1
 timeout -k 10 300 python bench.py --no-cpu-baseline --config sir > $O/bench_sir.json 2> $O/bench_sir.err || tail -5 $O/bench_sir.err
