@@ -10,6 +10,9 @@ namespace chmc {
 
 struct FhnModel {
   static constexpr int ID = 0, X = CHMC_FHN_X, V = CHMC_FHN_V, Z = CHMC_FHN_Z, V0 = CHMC_FHN_V0, NK = CHMC_FHN_NK;
+  static constexpr int NABS = 0;     // no absorbing components
+  CHMC_HD static bool absorbed(double) { return false; }
+  CHMC_HD static double abs_value() { return 0.0; }
   static constexpr int NXI = X + V + Z;
   static constexpr int U = Z;        // dim_u: the global parameters (fixed observation noise)
   static constexpr bool VS = false;  // variable observation noise
@@ -38,6 +41,9 @@ struct FhnModel {
 // one-step map, different generate_z / generate_x_0.
 struct FhnNbModel {
   static constexpr int ID = 2, X = CHMC_FHNNB_X, V = CHMC_FHNNB_V, Z = CHMC_FHNNB_Z, V0 = CHMC_FHNNB_V0, NK = CHMC_FHNNB_NK;
+  static constexpr int NABS = 0;     // no absorbing components
+  CHMC_HD static bool absorbed(double) { return false; }
+  CHMC_HD static double abs_value() { return 0.0; }
   static constexpr int NXI = X + V + Z;
   static constexpr int U = Z;        // dim_u: the global parameters (fixed observation noise)
   static constexpr bool VS = false;  // variable observation noise
@@ -70,6 +76,11 @@ struct SirModel {
   static constexpr int NXI = X + V + Z;
   static constexpr int U = Z;        // dim_u: the global parameters (fixed observation noise)
   static constexpr bool VS = false;  // variable observation noise
+  // the first NABS components are absorbing: once a state component is at or below the floor (or NaN: clip() below), every
+  // later state has it at abs_value() whatever the other components do (used by the time-parallel scan, k_fwd_par)
+  static constexpr int NABS = 2;
+  CHMC_HD static bool absorbed(double xa) { return !(xa > -500.0); }
+  CHMC_HD static double abs_value() { return -500.0; }
   CHMC_HD static void precompute(const double* z, double dl, double* k) { chmc_sir_precompute(z, dl, k); }
   CHMC_HD static void clip(const double* x, double* xc, bool* fr) {
     for (int a = 0; a < 2; ++a) {

@@ -3934,9 +3934,12 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
 // a chain's bits depend on the scan its shard selects (CHMC_PAR_SCAN fixes the choice; tests compare the two scans).
 // gsel: guess trajectory: 1 = the destination buffer itself (previous iterate), 2 = the state's trajectory (slot cur),
 // 3 = work.trajw (the last iterate of the retraction that produced the point being evaluated).
-template <class M, int RM>
-__global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int which, int qsel, int use_nw, int store_traj,
-                                                int gsel, int round) {
+// W wavefronts per (chain, block): 64 W segments, the affine prefix scan continued across the wavefronts through LDS (three
+// workgroup barriers per sweep).  The host picks W so that the launch has about one wavefront per SIMD of the chip
+// (chmc_create: par_waves); W = 1 compiles to the single-wavefront kernel (no LDS, no barrier).
+template <class M, int RM, int W>
+__global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, int which, int qsel, int use_nw,
+                                                    int store_traj, int gsel, int round) {
   // (ii) makes the sweeps exact after at most 64 of them, but a block that is not settled after a dozen belongs to a
   // chain whose retraction is diverging (healthy blocks settle in 2-9 sweeps): it is handed to the sequential
   // recursion, which costs the same 0.9 ms as the remaining sweeps would
@@ -3958,6 +3961,15 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
   const bool apend = (async || use_nw == 1) && sy.K == 1;
   const int MAXS = apend ? CHMC_PAR_MAXS_ROUND : 12;
   const int lane = threadIdx.x & 63;
+  const int wv = W > 1 ? (int)(threadIdx.x >> 6) : 0;  // wavefront of the workgroup
+  const int gl = W > 1 ? (int)threadIdx.x : lane;      // segment of the block
+  constexpr int NSEG = 64 * W;
+  // cross-wavefront hand-over (W > 1): first start state, scan aggregate, last new start state and the settled flag of
+  // every wavefront
+  __shared__ double sU[W > 1 ? W : 1][M::X], sAe[W > 1 ? W : 1][M::X], sAP[W > 1 ? W : 1][M::X * M::X],
+      sUn[W > 1 ? W : 1][M::X];
+  __shared__ int sFlag[W > 1 ? W : 1], sFront[W > 1 ? W : 1][1 + 2 * M::X];
+  __shared__ double sTv[W > 1 ? W : 1][M::X];
   const int wid = blockIdx.x;
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];
@@ -4005,16 +4017,20 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
 #pragma unroll
     for (int a = 0; a < X; ++a) x0[a] = xobs[(bd.obs0 - 1) * X + a];
   }
-  const int m = (L + 63) >> 6;                            // steps per segment
-  const int s0 = lane * m, s1 = (s0 + m < L ? s0 + m : L);  // this lane's segment [s0, s1) (empty when s0 >= L)
+  const int m = (L + NSEG - 1) / NSEG;                    // steps per segment
+  const int s0 = gl * m, s1 = (s0 + m < L ? s0 + m : L);  // this lane's segment [s0, s1) (empty when s0 >= L)
   const bool have = s0 < L;
   double Ul[X];  // start state of this lane's segment
 #pragma unroll
-  for (int a = 0; a < X; ++a) Ul[a] = lane == 0 ? x0[a] : (have ? guess[(size_t)s0 * X + a] : 0.0);
+  for (int a = 0; a < X; ++a) Ul[a] = gl == 0 ? x0[a] : (have ? guess[(size_t)s0 * X + a] : 0.0);
   bool converged = false;
   for (int sweep = 0; sweep < MAXS && !converged; ++sweep) {
     // exact recursion over the segment, its transition matrix, the trajectory entries and the constraint values
     double x[X], P[X * X];
+    if (W > 1 && lane == 0) {
+#pragma unroll
+      for (int a = 0; a < X; ++a) sU[wv][a] = Ul[a];
+    }
 #pragma unroll
     for (int a = 0; a < X; ++a) x[a] = Ul[a];
 #pragma unroll
@@ -4042,11 +4058,38 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
     double ec[X], Pc[X * X], Unext[X];
 #pragma unroll
     for (int a = 0; a < X; ++a) Unext[a] = __shfl_down(Ul[a], 1, 64);
+    if (W > 1) {
+      __syncthreads();  // (A) every wavefront's first start state is in sU
+      if (lane == 63 && wv + 1 < W) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) Unext[a] = sU[wv + 1][a];
+      }
+    }
     const bool junction = have && s1 < L;  // lane l + 1 owns a segment
 #pragma unroll
     for (int a = 0; a < X; ++a) ec[a] = junction ? x[a] - Unext[a] : 0.0;
 #pragma unroll
     for (int i = 0; i < X * X; ++i) Pc[i] = junction ? P[i] : ((i / X == i % X) ? 1.0 : 0.0);
+    // Models with absorbing components: a state may hold a NaN that the recursion itself removes (SIR clips a NaN
+    // compartment to the floor), so a NaN must not travel through the corrections: a junction that is NaN on both sides
+    // has no defect, and a segment whose defect or transition matrix is not finite passes no correction on (its end state
+    // goes to the next segment as it is).
+    bool broken = false;
+    if (M::NABS > 0 && junction) {
+#pragma unroll
+      for (int a = 0; a < X; ++a)
+        if (x[a] != x[a] && Unext[a] != Unext[a]) ec[a] = 0.0;
+#pragma unroll
+      for (int a = 0; a < X; ++a) broken = broken || !(fabs(ec[a]) <= 1.7976931348623157e308);
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) broken = broken || !(fabs(Pc[i]) <= 1.7976931348623157e308);
+      if (broken) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) ec[a] = 0.0;
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Pc[i] = 0.0;
+      }
+    }
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       double Pp[X * X], ep[X], Pn[X * X];
@@ -4067,13 +4110,51 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
         for (int i = 0; i < X * X; ++i) Pc[i] = Pn[i];
       }
     }
+    // across the wavefronts: d at the start of wavefront wv = the aggregates of the wavefronts before it applied to d_0 = 0
+    double dw[X];
+#pragma unroll
+    for (int a = 0; a < X; ++a) dw[a] = 0.0;
+    if (W > 1) {
+      if (lane == 63) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) sAe[wv][a] = ec[a];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) sAP[wv][i] = Pc[i];
+      }
+      __syncthreads();  // (B)
+      bool moved = false;  // (a zero d is passed on as an exact zero: no 0 * inf from an overflowed aggregate)
+      for (int k = 0; k < wv; ++k) {
+        double dn[X];
+#pragma unroll
+        for (int a = 0; a < X; ++a) {
+          double tt = sAe[k][a];
+          if (moved) {
+#pragma unroll
+            for (int d = 0; d < X; ++d) tt += sAP[k][a * X + d] * dw[d];
+          }
+          dn[a] = tt;
+        }
+        moved = false;
+#pragma unroll
+        for (int a = 0; a < X; ++a) dw[a] = dn[a], moved = moved || dn[a] != 0.0;
+      }
+      if (moved) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) {
+          double tt = ec[a];
+#pragma unroll
+          for (int d = 0; d < X; ++d) tt += Pc[a * X + d] * dw[d];
+          ec[a] = tt;
+        }
+      }
+    }
     // d_l of this lane = ec of lane l - 1; new start state of the NEXT lane's segment, formed as F_l + A_l d_l so that a
     // junction whose predecessor did not move (d_l == 0) receives exactly F_l
     double dl[X], Un[X];
 #pragma unroll
     for (int a = 0; a < X; ++a) {
       const double up = __shfl_up(ec[a], 1, 64);
-      dl[a] = lane == 0 ? 0.0 : up;
+      dl[a] = lane == 0 ? dw[a] : up;
     }
     bool still = true;  // this lane's start state did not move at all: its end state is final (exact prefix)
 #pragma unroll
@@ -4083,22 +4164,99 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
       double tt = 0.0;
 #pragma unroll
       for (int d = 0; d < X; ++d) tt += P[a * X + d] * dl[d];
-      Un[a] = still ? x[a] : x[a] + tt;  // (no 0 * inf from an overflowed transition matrix)
+      Un[a] = (still || broken) ? x[a] : x[a] + tt;  // (no 0 * inf from an overflowed transition matrix)
     }
     // A junction is settled when its new value equals the old one (bitwise, or both NaN: beyond a point where the true
     // recursion overflows everything is NaN and stays NaN) or differs by rounding only.  Segments started from garbage
     // may overflow; that is not an error: the exact prefix grows by at least one segment per sweep and reaches them.
-    int unsettled = 0;
+    // (Judged by the lane that produced the new value: it holds the old start state of the next segment in Unext.)
+    auto moved_beyond_rounding = [&]() {
+      int u = 0;
+      if (junction) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) {
+          const double nu = Un[a], old = Unext[a];
+          const bool same = nu == old || (nu != nu && old != old);
+          const bool close = fabs(nu - old) <= 1e-13 * (fabs(nu) > 1.0 ? fabs(nu) : 1.0);
+          u |= !(same || close);
+        }
+      }
+      return u;
+    };
+    int unsettled = moved_beyond_rounding();
+    // Absorbing components (SIR: a log-compartment that has reached the floor stays there, with zero derivatives; a
+    // component without a floor that is NaN stays NaN).  The linearised junction conditions carry no information through
+    // such a component, so a guess that is absorbed where the trajectory is not (or the other way round) would be corrected
+    // ONE segment per sweep: measured, every scan left unsettled after 12 sweeps had such a front -- settled junctions up
+    // to segment 40 or so, one or two unsettled ones, and start states at the floor (left by the previous Newton iterate)
+    // or NaN from there on.  So, once everything before such a junction has settled (the segment to its left is then
+    // trusted):
+    //  * freeze: the first segment that ENDS absorbed makes every later segment start absorbed, whatever the other
+    //    components do: those start states are set to the absorbed value at once (on the exact prefix that is the value the
+    //    recursion gives anyway);
+    //  * thaw: at the first junction whose new value is not absorbed while the old one was, the later start states that
+    //    would stay absorbed take that junction's value as their guess, and the ordinary iteration goes on from there.
+    // Both only change guesses: a junction still counts as settled only when its new value equals its old one.
+    if (M::NABS > 0) {
+      constexpr int NONE = 0x7fffffff;
+      const double qnan = __longlong_as_double(0x7ff8000000000000LL);
+      auto stuck = [](int a, double v) { return a < M::NABS ? M::absorbed(v) : v != v; };
+      const unsigned long long bu = __ballot(unsettled);
+      int fu = bu ? __ffsll((long long)bu) - 1 + 64 * wv : NONE;  // first junction (by its left segment) that moved
+      int fa[X], ft[X];  // first segment that ends absorbed / first thawing junction, per component
+      double tv[X];      // new value of the thawing junction
+#pragma unroll
+      for (int a = 0; a < X; ++a) {
+        const unsigned long long ba = __ballot(have && stuck(a, x[a]));
+        fa[a] = ba ? __ffsll((long long)ba) - 1 + 64 * wv : NONE;
+        const unsigned long long bt = __ballot(junction && !stuck(a, Un[a]) && stuck(a, Unext[a]));
+        const int lt = bt ? __ffsll((long long)bt) - 1 : 0;
+        ft[a] = bt ? lt + 64 * wv : NONE;
+        tv[a] = __shfl(Un[a], lt, 64);
+      }
+      if (W > 1) {
+        if (lane == 0) {
+          sFront[wv][0] = fu;
+#pragma unroll
+          for (int a = 0; a < X; ++a) sFront[wv][1 + a] = fa[a], sFront[wv][1 + X + a] = ft[a], sTv[wv][a] = tv[a];
+        }
+        __syncthreads();  // (B')
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+          fu = sFront[k][0] < fu ? sFront[k][0] : fu;
+#pragma unroll
+          for (int a = 0; a < X; ++a) {
+            fa[a] = sFront[k][1 + a] < fa[a] ? sFront[k][1 + a] : fa[a];
+            if (sFront[k][1 + X + a] < ft[a]) ft[a] = sFront[k][1 + X + a], tv[a] = sTv[k][a];
+          }
+        }
+      }
+      bool changed = false;
+#pragma unroll
+      for (int a = 0; a < X; ++a) {
+        if (!junction) continue;
+        if (fa[a] != NONE && fu >= fa[a]) {
+          if (gl > fa[a]) Un[a] = a < M::NABS ? M::abs_value() : qnan, changed = true;
+        } else if (ft[a] != NONE && fu >= ft[a]) {
+          if (gl > ft[a] && stuck(a, Un[a])) Un[a] = tv[a], changed = true;
+        }
+      }
+      if (changed) unsettled = moved_beyond_rounding();
+    }
+    const bool wave_unsettled = __ballot(unsettled) != 0ULL;
+    if (W > 1) {
+      if (lane == 63) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) sUn[wv][a] = Un[a];
+        sFlag[wv] = wave_unsettled;
+      }
+      __syncthreads();  // (C)
+    }
 #pragma unroll
     for (int a = 0; a < X; ++a) {
-      const double nu = __shfl_up(Un[a], 1, 64);  // new start state of this lane's segment
-      if (lane > 0 && have) {
-        const double old = Ul[a];
-        const bool same = nu == old || (nu != nu && old != old);
-        const bool close = fabs(nu - old) <= 1e-13 * (fabs(nu) > 1.0 ? fabs(nu) : 1.0);
-        unsettled |= !(same || close);
-        Ul[a] = nu;
-      }
+      double nu = __shfl_up(Un[a], 1, 64);  // new start state of this lane's segment
+      if (W > 1 && lane == 0 && wv > 0) nu = sUn[wv - 1][a];
+      if (gl > 0 && have) Ul[a] = nu;
     }
     // end of the block: the segment that contains step L - 1 has just produced it (from its OLD start state; it is
     // final once the sweep that follows convergence... the loop below only leaves when no junction moved)
@@ -4112,25 +4270,32 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
     }
     // converged: no junction moved (beyond rounding), so what this sweep stored IS the trajectory of the start states
     // it used
-    converged = __ballot(unsettled) == 0ULL;
-    if (converged && lane == 0 && w.nfallback) atomicAdd(w.nfallback + 1 + (sweep < 14 ? sweep : 14) + 16 * (gsel - 1), 1);
+    if (W > 1) {
+      int any = 0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) any |= sFlag[k];
+      converged = !any;
+    } else {
+      converged = !wave_unsettled;
+    }
+    if (converged && gl == 0 && w.nfallback) atomicAdd(w.nfallback + 1 + (sweep < 14 ? sweep : 14) + 16 * (gsel - 1), 1);
   }
   if (apend) {
     if (!converged) {
       // keep the junction states for the next round's sweeps (the guess is then this buffer: gsel 1)
-      if (lane > 0 && have) {
+      if (gl > 0 && have) {
 #pragma unroll
         for (int a = 0; a < X; ++a) traj[(size_t)s0 * X + a] = Ul[a];
       }
-      if (lane == 0) {
+      if (gl == 0) {
         *amask = 2;
         if (w.nfallback) atomicAdd(w.nfallback + 15, 1);
       }
       return;
     }
-    if (lane == 0) *amask = 1;
+    if (gl == 0) *amask = 1;
   }
-  if (!converged && lane == 0) {  // sequential recursion (same arithmetic as fwd_block_impl)
+  if (!converged && gl == 0) {  // sequential recursion (same arithmetic as fwd_block_impl)
     double x[X], xn[X];
 #pragma unroll
     for (int a = 0; a < X; ++a) x[a] = x0[a];
@@ -4153,7 +4318,7 @@ __global__ void __launch_bounds__(64) k_fwd_par(Sys sy, Slots sl, Work w, int wh
     }
     if (w.nfallback) atomicAdd(w.nfallback, 1);
   }
-  if (lane == 0)
+  if (gl == 0)
     for (int i = bd.nrows; i < RM; ++i) out[i] = 0.0;  // padded constraint slots
 }
 

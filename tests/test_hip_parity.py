@@ -849,3 +849,55 @@ def test_time_parallel_scan_against_the_sequential_scan(monkeypatch):
     assert (ra[0]["status"][[9, 33]] > 0).all()
     if differ == 0:
         assert np.abs(qa - qb).max() <= 1e-9 * max(1.0, np.abs(qb).max())
+
+
+def test_time_parallel_scan_absorbed_and_nan_trajectories(monkeypatch):
+    """k_fwd_par on trajectories with absorbed compartments (SIR clips log S and log I at -500 and keeps a clipped
+    component where it is, sde/example_models/sir.py:54-70) and with NaNs, from guesses that are absorbed where the
+    trajectory is not and the other way round: the unconstrained target (one forward scan of T S = 2 800 steps per chain,
+    conditioned_diffusion_neg_log_dens_and_grad, sde/mici_extensions.py:82-205) of healthy, wild, then healthy points
+    again -- every scan is seeded with the previous call's trajectory -- with 1, 2 and 4 wavefronts per chain against the
+    sequential scan: same NaN pattern, values and gradients to 1e-9; two chains per call against the autodiff oracle."""
+    from oracle.py.neg_log_dens import neg_log_dens_and_grad
+    B, T, S = 96, 14, 200
+    case = make_case("sir", T, S, 14, True, B=B, seed=5, obs_interval=0.25)
+    rng = np.random.default_rng(77)
+    QH = None
+    calls = None
+    results = {}
+    for mode in ("seq", "1", "2", "4"):
+        monkeypatch.setenv("CHMC_PAR_SCAN", "0" if mode == "seq" else "1")
+        monkeypatch.setenv("CHMC_PAR_WAVES", "1" if mode == "seq" else mode)
+        ctx = make_ctx(case)
+        if calls is None:
+            QH = ctx.U + ctx.NV
+            scale = np.repeat([0.5, 2.0, 4.0, 8.0], B // 4)[:, None]
+            healthy = 0.5 * rng.standard_normal((B, QH))
+            wild = scale * rng.standard_normal((B, QH))
+            wild[:, :ctx.U] = scale * rng.standard_normal((B, ctx.U)) * 2.0
+            calls = [healthy, wild, healthy + 0.01 * rng.standard_normal((B, QH)), wild[::-1].copy(), healthy]
+        results[mode] = [ctx.neg_log_dens_and_grad(q) for q in calls]
+        if mode != "seq":
+            assert int(ctx.diagnostics()["par_scan"][1:48].sum()) > 0
+        ctx.close()
+    n_nan = 0
+    for i, q in enumerate(calls):
+        v0, g0 = results["seq"][i]
+        n_nan += int(np.isnan(v0).sum())
+        for mode in ("1", "2", "4"):
+            v, g = results[mode][i]
+            np.testing.assert_array_equal(np.isnan(v), np.isnan(v0), err_msg=f"call {i} W={mode}")
+            ok = ~np.isnan(v0)
+            assert np.abs(v[ok] - v0[ok]).max() <= 1e-9 * np.maximum(1.0, np.abs(v0[ok])).max(), (i, mode)
+            gs = np.maximum(1.0, np.nanmax(np.abs(g0[ok]), axis=1, keepdims=True))
+            np.testing.assert_array_equal(np.isnan(g[ok]), np.isnan(g0[ok]), err_msg=f"call {i} W={mode}")
+            assert np.nanmax(np.abs(g[ok] - g0[ok]) / gs) <= 1e-9, (i, mode)
+        for c in (0, B - 1):
+            vo, go = neg_log_dens_and_grad("sir", case["obs_interval"], S, case["y"], case["sigma"], q[c], False)
+            if np.isnan(vo):
+                assert np.isnan(v0[c])
+            else:
+                assert abs(v0[c] - vo) <= 1e-9 * max(1.0, abs(vo)), (i, c, v0[c], vo)
+    # the wild calls must actually contain absorbed / overflowing trajectories, or the test shows nothing
+    xs = results["seq"][1][0]
+    assert np.isfinite(xs).sum() >= B // 4

@@ -62,6 +62,59 @@ def test_checker_accepts_a_correct_ring_and_flags_violations():
     assert "uses scratch memory" in t.check_kernel("k", bad.split("\n"))
 
 
+# the same ring with the first trip peeled and parked BEHIND the loop (what hipcc does to k_fwd_scan when the kernel
+# argument layout shifts its scheduling): in layout order the loop body seems to consume v[10:13] with both loads in flight
+PEELED = """
+k:
+	;;#ASMSTART
+	global_load_dwordx4 v[10:13], v[0:1], off offset:0
+	;;#ASMEND
+	;;#ASMSTART
+	global_load_dwordx4 v[14:17], v[0:1], off offset:16
+	;;#ASMEND
+	s_branch .LBB0_3
+.LBB0_1:
+	;;#ASMSTART
+	s_waitcnt vmcnt(1)
+	;;#ASMEND
+	v_fma_f64 v[20:21], v[10:11], v[12:13], v[20:21]
+	;;#ASMSTART
+	global_load_dwordx4 v[10:13], v[0:1], off offset:32
+	;;#ASMEND
+.LBB0_2:
+	;;#ASMSTART
+	s_waitcnt vmcnt(1)
+	;;#ASMEND
+	v_fma_f64 v[20:21], v[14:15], v[16:17], v[20:21]
+	;;#ASMSTART
+	global_load_dwordx4 v[14:17], v[0:1], off offset:48
+	;;#ASMEND
+	s_cbranch_scc1 .LBB0_1
+	s_waitcnt vmcnt(0)
+	s_endpgm
+.LBB0_3:
+	;;#ASMSTART
+	s_waitcnt vmcnt(1)
+	;;#ASMEND
+	v_fma_f64 v[20:21], v[10:11], v[12:13], v[20:21]
+	;;#ASMSTART
+	global_load_dwordx4 v[10:13], v[0:1], off offset:32
+	;;#ASMEND
+	s_branch .LBB0_2
+"""
+
+
+def test_checker_follows_the_control_flow_of_peeled_loops():
+    t = _tool()
+    assert t.check_kernel("k", PEELED.split("\n")) == []
+    # a violation inside the parked block is still found
+    bad = PEELED.replace("\ts_branch .LBB0_2", "\tv_mov_b32_e32 v30, v11\n\ts_branch .LBB0_2")
+    assert any("in-flight" in p for p in t.check_kernel("k", bad.split("\n")))
+    # and so is a missing wait on the path through it
+    bad = PEELED.replace(".LBB0_3:\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(1)", ".LBB0_3:\n\t;;#ASMSTART\n\ts_waitcnt vmcnt(2)")
+    assert any("in-flight" in p for p in t.check_kernel("k", bad.split("\n")))
+
+
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
 def test_forward_scan_kernels_keep_in_flight_registers_untouched():
     r = subprocess.run([sys.executable, TOOL], capture_output=True, text=True, timeout=900)

@@ -11,7 +11,8 @@ every k_fwd_scan kernel's instruction stream:
   * any other instruction that reads or writes a register of a load still in the FIFO is a violation;
   * the kernels must not use scratch memory.
 
-Loop bodies are replayed twice so that registers carried around the back edge are covered.
+The replay follows the control flow (both ways at every conditional branch, every (position, loads in flight) state once),
+so peeled or rotated loops are covered whatever order the compiler lays the blocks out in.
 
 Second audit, for every kernel that issues stores the compiler does not see (`st_async` in the reverse sweeps and the
 forward grad-log-det sweep): counted waits stay valid next to an untracked store only because loads
@@ -61,41 +62,67 @@ def check_kernel(name, body):
                 stream.append(("label", t[:-1], False))
             continue
         stream.append(("ins", t, in_asm))
-    # replay; loops: a backward branch target seen earlier -> replay that span once more
+    # replay along the control flow: every path from the entry, a (position, loads in flight) pair is expanded once.  (A
+    # replay in layout order -- the first version of this guard -- reported loads "in flight" at their consumers whenever
+    # the compiler peeled the first trip of the ring loop and parked the peeled blocks behind the loop.)
     labels = {t: i for i, (k, t, _) in enumerate(stream) if k == "label"}
-    order = list(range(len(stream)))
-    for i, (k, t, _) in enumerate(stream):
-        if k == "ins" and t.startswith("s_cbranch"):
-            tgt = t.split()[-1]
-            if tgt in labels and labels[tgt] < i:
-                order += list(range(labels[tgt], i + 1))
-    fifo = []  # list of register sets of in-flight asm loads
-    n_loads = 0
-    for idx in order:
-        k, t, in_asm = stream[idx]
-        if k != "ins":
-            continue
-        if in_asm and t.startswith("global_load_dwordx4"):
-            dst = regs_of(t.split(",")[0])
-            fifo.append(dst)
-            n_loads += 1
-            continue
-        m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
-        if m:
-            n = int(m.group(1))
-            if in_asm:
-                del fifo[: max(0, len(fifo) - n)]
-            elif n == 0:
-                fifo.clear()
-            continue
-        if t.startswith(("s_", "ds_")) and "v" not in t.split(None, 1)[-1]:
-            continue
-        if fifo:
-            used = regs_of(t.split(None, 1)[1] if " " in t else "")
-            for dst in fifo:
-                if used & dst:
-                    problems.append(f"touches in-flight load registers {sorted(used & dst)[:4]}: {t}")
+    n_loads = sum(1 for k, t, a in stream if k == "ins" and a and t.startswith("global_load_dwordx4"))
+    seen, reported = set(), set()
+    work = [(0, ())]
+    while work:
+        idx, fifo = work.pop()
+        fifo = list(fifo)
+        while idx < len(stream):
+            k, t, in_asm = stream[idx]
+            if k == "label":
+                key = (idx, tuple(fifo))
+                if key in seen:
                     break
+                seen.add(key)
+                if len(seen) > 400000:
+                    problems.append("control-flow replay did not terminate (state explosion)")
+                    work = []
+                    break
+                idx += 1
+                continue
+            if t.startswith("s_endpgm"):
+                break
+            if t.startswith("s_branch"):
+                idx = labels[t.split()[-1]]
+                continue
+            if t.startswith("s_cbranch"):
+                work.append((labels[t.split()[-1]], tuple(fifo)))
+                idx += 1
+                key = (idx, tuple(fifo))
+                if key in seen:
+                    break
+                seen.add(key)
+                continue
+            if t.startswith(("s_setpc", "s_swappc")):
+                problems.append(f"indirect jump / call in a kernel with hand-issued loads: {t}")
+                break
+            idx += 1
+            if in_asm and t.startswith("global_load_dwordx4"):
+                fifo.append(frozenset(regs_of(t.split(",")[0])))
+                continue
+            m = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
+            if m:
+                n = int(m.group(1))
+                if in_asm:
+                    del fifo[: max(0, len(fifo) - n)]
+                elif n == 0:
+                    fifo.clear()
+                continue
+            if t.startswith(("s_", "ds_")) and "v" not in t.split(None, 1)[-1]:
+                continue
+            if fifo:
+                used = regs_of(t.split(None, 1)[1] if " " in t else "")
+                for dst in fifo:
+                    if used & dst:
+                        if t not in reported:
+                            reported.add(t)
+                            problems.append(f"touches in-flight load registers {sorted(used & dst)[:4]}: {t}")
+                        break
     if n_loads == 0:
         problems.append("no hand-issued loads found (kernel changed?)")
     return problems
