@@ -3725,8 +3725,8 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
   constexpr int RSD = PF * X + 2;        // LDS row stride in doubles: tile + 16 bytes (conflict-free row access)
   static_assert(NOUT <= 63, "vmcnt is a 6-bit field");
 #ifndef CHMC_SCAN_NB
-#define CHMC_SCAN_NB 1  // 2 and 4 measured 5 % faster per launch at configs[1], but tools/check_scan_isa.py finds the
-                        // compiler reusing in-flight ring registers at those settings (FHN, VARSIG builds): rejected
+#define CHMC_SCAN_NB 1  // 2 measured equal within the run-to-run spread (three interleaved runs each at configs[1]:
+                        // 45.9-46.2 k against 45.3-46.2 k steps/s; S = 800, 512 chains: 27.82 k against 27.83 k)
 #endif
   // NB tiles per hand-over: the integrating wave parks NB tiles before it meets the helper at the barrier, so the helper
   // may fall up to NB tiles behind (store issue under memory load) without stalling the recursion

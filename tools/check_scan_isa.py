@@ -22,7 +22,7 @@ for flat_ ones -- and the store's data registers may be rewritten only after the
     code, can be scheduled between the two);
   * the kernel contains no flat_ memory instruction;
   * spill code (scratch_) is reported; the instantiations listed in NO_SPILL must have none.
-usage: check_scan_isa.py [chmc.hip]      exit status 0 = clean"""
+usage: check_scan_isa.py [chmc.hip] [-DNAME=VALUE ...]      exit status 0 = clean"""
 import os
 import re
 import subprocess
@@ -150,11 +150,13 @@ def audit_stores(name, body):
 
 
 def main():
-    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "manifold_mcmc_for_diffusions_amd", "csrc", "chmc.hip")
+    defs = [a for a in sys.argv[1:] if a.startswith("-D")]  # (variant builds: -DCHMC_SCAN_NB=2 ...)
+    args = [a for a in sys.argv[1:] if not a.startswith("-D")]
+    src = args[0] if args else os.path.join(ROOT, "manifold_mcmc_for_diffusions_amd", "csrc", "chmc.hip")
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "chmc.s")
         subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "-S", "--cuda-device-only",
-                               "-o", out, src])
+                               "-o", out, src] + defs)
         lines = open(out).read().split("\n")
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN4chmc10k_fwd_scan\w*:", l)]
     bad = 0
