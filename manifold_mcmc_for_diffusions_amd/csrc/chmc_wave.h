@@ -1062,7 +1062,10 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
 #ifndef CHMC_IVL_WAVES
 #define CHMC_IVL_WAVES 2
 #endif
-template <class M>
+// STATE (both phases): the state evaluation of slot `which` in the same two phases (k_newton_lean<.., STATE> for blocks of
+// any RM <= 16): phase A also WRITES the compact rows PB[s] = T_s and sums T_s T_s^T; phase B writes the frames LF[m], the
+// symmetric Gram block, the rows' v_0 columns, the dc/du rows of the slot and the dc/dz rows (work.zbP).
+template <class M, bool STATE = false>
 __global__ void __launch_bounds__(64, CHMC_IVL_WAVES) k_newton_ivl(Sys sy, Slots sl, Work w, int which, int qsel) {
   constexpr int X = M::X, V = M::V, Z = M::Z;
   const int lane = threadIdx.x & 63;
@@ -1071,15 +1074,15 @@ __global__ void __launch_bounds__(64, CHMC_IVL_WAVES) k_newton_ivl(Sys sy, Slots
   const int m = wid % sy.NOBS;
   const int cbi = sy.order[wid / sy.NOBS];
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (!newton_select(w, c, which, qsel)) return;
+  if (STATE ? !w.ok[c] : !newton_select(w, c, which, qsel)) return;
   const BlockDesc bd = sy.blk[b];
   if (m >= bd.nobs) return;
   const int sl_ = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
   const int S = sy.S;
-  const double* q = (qsel ? w.qb : pick(sl.q, sl_ ^ 1)) + (size_t)c * sy.Q;
-  const double* traj = w.trajw + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X + (size_t)m * S * X;
-  const double* PBr = pick(sl.PB, sl_) + ((size_t)c * sy.T * S + bd.step0 + (size_t)m * S) * (X * V);
+  const double* q = (STATE ? pick(sl.q, sl_) : (qsel ? w.qb : pick(sl.q, sl_ ^ 1))) + (size_t)c * sy.Q;
+  const double* traj = (STATE ? pick(sl.traj, sl_) : w.trajw) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X + (size_t)m * S * X;
+  double* PBr = pick(sl.PB, sl_) + ((size_t)c * sy.T * S + bd.step0 + (size_t)m * S) * (X * V);  // (STATE: written)
   const double* vbase = q + sy.U + sy.V0 + ((size_t)bd.step0 + (size_t)m * S) * V;
   ChainConsts<M> cc;
   cc.init(q, sy.dl);
@@ -1101,8 +1104,10 @@ __global__ void __launch_bounds__(64, CHMC_IVL_WAVES) k_newton_ivl(Sys sy, Slots
       for (int a = 0; a < X; ++a) r.x[a] = ld_stream(traj + (size_t)off * X + a);
 #pragma unroll
       for (int a = 0; a < V; ++a) r.v[a] = vbase[(size_t)off * V + a];
+      if constexpr (!STATE) {
 #pragma unroll
-      for (int k = 0; k < X * V; ++k) r.jp[k] = ld_stream(PBr + (size_t)off * (X * V) + k);
+        for (int k = 0; k < X * V; ++k) r.jp[k] = ld_stream(PBr + (size_t)off * (X * V) + k);
+      }
     } else {
 #pragma unroll
       for (int a = 0; a < X; ++a) r.x[a] = 0.0;
@@ -1150,13 +1155,20 @@ __global__ void __launch_bounds__(64, CHMC_IVL_WAVES) k_newton_ivl(Sys sy, Slots
         for (int e = 0; e < X; ++e) tt2 += PE[a * X + e] * Zf[e * Z + mz];
         Wacc[a * Z + mz] = tt2;
       }
+    if constexpr (STATE) {
+      if (r0.valid) {  // PB[s] = T_s: the compact form of this step's rows (Slots::PB)
+        double* dst = PBr + (size_t)((t << 6) + (63 - lane)) * (X * V);
+#pragma unroll
+        for (int k = 0; k < X * V; ++k) dst[k] = T[k];
+      }
+    }
 #pragma unroll
     for (int a = 0; a < X; ++a)
 #pragma unroll
       for (int a2 = 0; a2 < X; ++a2) {
         double tt2 = Sacc[a * X + a2];
 #pragma unroll
-        for (int d = 0; d < V; ++d) tt2 += T[a * V + d] * r0.jp[a2 * V + d];
+        for (int d = 0; d < V; ++d) tt2 += T[a * V + d] * (STATE ? T[a2 * V + d] : r0.jp[a2 * V + d]);
         Sacc[a * X + a2] = tt2;
       }
     {
@@ -1188,7 +1200,7 @@ __global__ void __launch_bounds__(64, CHMC_IVL_WAVES) k_newton_ivl(Sys sy, Slots
   }
 }
 
-template <class M, int RM>
+template <class M, int RM, bool STATE = false>
 __global__ void __launch_bounds__(64) k_newton_comb(Sys sy, Slots sl, Work w, int which, int qsel) {
   constexpr int X = M::X, Z = M::Z, U = M::U, V0 = M::V0;
   constexpr int NI = CHMC_IVL_N(X, Z);
@@ -1198,15 +1210,15 @@ __global__ void __launch_bounds__(64) k_newton_comb(Sys sy, Slots sl, Work w, in
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (!newton_select(w, c, which, qsel)) return;
+  if (STATE ? !w.ok[c] : !newton_select(w, c, which, qsel)) return;
   const BlockDesc bd = sy.blk[b];
   const int sl_ = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
   const int S = sy.S, NV = sy.NV;
-  const double* q = (qsel ? w.qb : pick(sl.q, sl_ ^ 1)) + (size_t)c * sy.Q;
-  const double* traj = w.trajw + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
-  const double* Jr = pick(sl.Jv, sl_) + (size_t)c * RM * NV;
-  const double* LFr = pick(sl.LF, sl_) + cb * sy.NOBS * RM * X;
+  const double* q = (STATE ? pick(sl.q, sl_) : (qsel ? w.qb : pick(sl.q, sl_ ^ 1))) + (size_t)c * sy.Q;
+  const double* traj = (STATE ? pick(sl.traj, sl_) : w.trajw) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  double* Jr = pick(sl.Jv, sl_) + (size_t)c * RM * NV;  // (STATE: the v_0 columns are written)
+  double* LFr = pick(sl.LF, sl_) + cb * sy.NOBS * RM * X;  // (STATE: written)
   auto lds_sync = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -1230,10 +1242,13 @@ __global__ void __launch_bounds__(64) k_newton_comb(Sys sy, Slots sl, Work w, in
     const double* iv = w.ivl + (cb * sy.NOBS + m) * NI;
     for (int e = lane; e < NI; e += 64) Iv[e] = iv[e];
     lds_sync();
-    // Ys[jj][a] = sum_a2 Ss[a][a2] LFprev[m][jj][a2]
+    if constexpr (STATE) {  // the frame of interval m (Slots::LF)
+      for (int e = lane; e < RM * X; e += 64) LFr[(size_t)m * RM * X + e] = LamF[e];
+    }
+    // Ys[jj][a] = sum_a2 Ss[a][a2] LFprev[m][jj][a2]   (STATE: the point's own frame)
     for (int e = lane; e < RM * X; e += 64) {
       const int jj = e / X, a = e - jj * X;
-      const double* lf = LFr + ((size_t)m * RM + jj) * X;
+      const double* lf = STATE ? LamF + jj * X : LFr + ((size_t)m * RM + jj) * X;
       double tt = 0.0;
 #pragma unroll
       for (int a2 = 0; a2 < X; ++a2) tt += Iv[a * X + a2] * lf[a2];
@@ -1274,9 +1289,10 @@ __global__ void __launch_bounds__(64) k_newton_comb(Sys sy, Slots sl, Work w, in
       const int i = e / RM, jj = e - i * RM;
       double tt = Dl[e];
       for (int d = 0; d < V0; ++d) {
-        double j0 = 0.0;
-        for (int a = 0; a < X; ++a) j0 += LamF[i * X + a] * dv0[a * V0 + d];
-        tt += j0 * Jr[(size_t)jj * NV + d];
+        double j0 = 0.0, j1 = 0.0;
+        for (int a = 0; a < X; ++a) j0 += LamF[i * X + a] * dv0[a * V0 + d], j1 += LamF[jj * X + a] * dv0[a * V0 + d];
+        tt += j0 * (STATE ? j1 : Jr[(size_t)jj * NV + d]);
+        if (STATE && jj == 0) Jr[(size_t)i * NV + d] = j0;  // the rows' v_0 columns
       }
       Dl[e] = tt;
     }
@@ -1318,7 +1334,10 @@ __global__ void __launch_bounds__(64) k_newton_comb(Sys sy, Slots sl, Work w, in
     } else {
       tt = i < bd.ny ? sigma_at(sy, q) * q[sy.U + sy.NV + bd.obs0 + i] : 0.0;
     }
-    w.JuL[cb * RM * U + e] = tt;
+    (STATE ? pick(sl.JuP, sl_) : w.JuL)[cb * RM * U + e] = tt;
+  }
+  if constexpr (STATE) {
+    for (int e = lane; e < RM * Z; e += 64) w.zbP[cb * RM * Z + e] = zl[e];
   }
 }
 
@@ -3030,6 +3049,314 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave_ldsrows(Sys sy, Slots sl, 
     zbt[i] = v;
   }
   if (lane == 0) {
+    double Gz[Z * Z], gu[U];
+    M::gz_jac(q, Gz);
+    for (int d = 0; d < Z; ++d) {
+      double tt = 0.0;
+      for (int mz = 0; mz < Z; ++mz) tt += Gz[mz * Z + d] * zbt[mz];
+      gu[d] = tt;
+    }
+    for (int i = 0; i < RM; ++i) {
+      double o[Z], wu[U], zb[Z];
+      for (int d = 0; d < U; ++d) wu[d] = w.gWu[(cb * RM + i) * U + d];
+      for (int mz = 0; mz < Z; ++mz) zb[mz] = w.zbP[(cb * RM + i) * Z + mz];
+      M::gz_hess(q, wu, zb, o);
+      for (int d = 0; d < Z; ++d) gu[d] += o[d];
+    }
+    if constexpr (M::VS)  // variable observation noise: the sigma-dependent entries of J (see var_sigma_grad_terms)
+      gu[Z] = var_sigma_grad_terms<RM>(sy, bd, q, w.gWu + cb * RM * U, U, w.gMb + cb * RM * RM,
+                                       pick(sl.grad, s_) + (size_t)c * sy.Q);
+    for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
+  }
+}
+
+// The 16-row backward sweep with the rows of a block dealt out to the NSPLIT wavefronts of one workgroup (few long blocks:
+// the SIR single-block layout leaves three quarters of the SIMDs empty at one wavefront per block).  Everything the sweep
+// accumulates is LINEAR in the per-row terms -- the Hessian contraction source Sm, hence H, the second-order adjoint x-bar
+// with its carries, the gradient entries and z-bar -- so every wavefront runs the whole recursion for ITS rows (RH adjoint
+// rows in registers, fully unrolled: no run-time row index, no LDS row state) and the partial gradient entries of a tile are
+// summed through LDS in a fixed order (one workgroup barrier per tile, double-buffered).  The step's own derivatives
+// (jac, prefix products, Hessian contraction) are recomputed by every wavefront; the weights w_i come from the compact rows
+// (MLF[m] PB[s], as in the forward sweep) and only the wavefront's own tangents are read.
+template <class M, int RM, int NSPLIT>
+__global__ void __launch_bounds__(64 * NSPLIT) k_gld_bwd_wave_rowsplit(Sys sy, Slots sl, Work w, int which) {
+  constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0, NXI = M::NXI;
+  constexpr int RH = RM / NSPLIT;
+  static_assert(RM % NSPLIT == 0 && NSPLIT > 1, "equal shares of the rows");
+  __shared__ double sm[NSPLIT][RM * RM + RM * Z + RM * X];
+  __shared__ double sG[2][NSPLIT - 1][V][64];
+  __shared__ double sEnd[NSPLIT][X + Z];
+  const int lane = threadIdx.x & 63;
+  const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r0 = h * RH;
+  const int wid = blockIdx.x;
+  if (wid >= sy.B * sy.K) return;
+  const int cbi = sy.order[wid];  // work order: longest blocks first
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (!w.ok[c]) return;  // (the whole workgroup)
+  const BlockDesc bd = sy.blk[b];
+  const int s_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int S = sy.S;
+  const size_t TS = (size_t)sy.T * S;
+  const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
+  const double* Xd = w.Xd + (size_t)c * RM * X * TS + bd.step0;
+  const double* PBr = pick(sl.PB, s_) + ((size_t)c * TS + bd.step0) * (X * V);
+  const double* LFr = pick(sl.LF, s_) + cb * sy.NOBS * RM * X;
+  double* gv = pick(sl.grad, s_) + (size_t)c * sy.Q + sy.U;
+  double* Mb = sm[h];
+  double* zd = sm[h] + RM * RM;
+  double* MLFs = sm[h] + RM * RM + RM * Z;
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int i = lane; i < RM * RM; i += 64) Mb[i] = w.gMb[cb * RM * RM + i];
+  for (int i = lane; i < RM * Z; i += 64) zd[i] = w.gzd[cb * RM * Z + i];
+  lds_sync();
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  double Lam[RH * X], zdr[RH * Z], mlf[RH * X];  // this wavefront's adjoint rows (wave-uniform), z-tangents, weights' frames
+#pragma unroll
+  for (int i = 0; i < RH * X; ++i) Lam[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < RH * Z; ++i) zdr[i] = zd[r0 * Z + i];
+  double xb[X], zbt[Z];
+#pragma unroll
+  for (int i = 0; i < X; ++i) xb[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < Z; ++i) zbt[i] = 0.0;
+  const int ntile = (S + 63) >> 6;
+  int buf = 0;
+  for (int j = bd.nobs - 1; j >= 0; --j) {
+    if (j < bd.ny && j >= r0 && j < r0 + RH) {  // the observation row of this interval's end belongs to this wavefront
+      double g[X], hv[X], xt[X];
+      for (int a = 0; a < X; ++a) xt[a] = w.gxdt[(cb * RM + j) * X + a];
+      M::obs_grad(traj + (size_t)(j + 1) * S * X, g);
+      M::obs_hess_vec(traj + (size_t)(j + 1) * S * X, xt, hv);
+#pragma unroll
+      for (int i = 0; i < RH; ++i)
+        if (r0 + i == j) {
+#pragma unroll
+          for (int a = 0; a < X; ++a) Lam[i * X + a] = g[a];
+        }
+#pragma unroll
+      for (int a = 0; a < X; ++a) xb[a] += hv[a];
+    }
+    if (j == bd.nobs - 1 && !bd.last) {  // state rows ny .. ny + X of a block that ends inside the sequence
+#pragma unroll
+      for (int i = 0; i < RH; ++i)
+#pragma unroll
+        for (int a = 0; a < X; ++a)
+          if (r0 + i == bd.ny + a) Lam[i * X + a] = 1.0;
+    }
+    {  // MLF[j] = (G^-1)_bb LF[j], one entry per lane, then this wavefront's rows to registers
+      lds_sync();
+      if (lane < RM * X) {
+        const int i = lane / X, a = lane - i * X;
+        double t = 0.0;
+        for (int jj = 0; jj < RM; ++jj) t += Mb[i * RM + jj] * LFr[((size_t)j * RM + jj) * X + a];
+        MLFs[lane] = t;
+      }
+      lds_sync();
+#pragma unroll
+      for (int e2 = 0; e2 < RH * X; ++e2) mlf[e2] = MLFs[r0 * X + e2];
+    }
+    for (int t = ntile - 1; t >= 0; --t) {
+      const int off = (t << 6) + (63 - lane);  // LATER steps in LOWER lanes: the suffix scans become DPP prefix scans
+      const bool valid = off < S;
+      const int s = j * S + off;
+      const size_t col = colb + (size_t)s * V;
+      double A[X * X], Bm[X * V], Zf[X * Z], x[X], vv[V], pb[X * V];
+      if (valid) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) x[a] = ld_stream(traj + (size_t)s * X + a);
+#pragma unroll
+        for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
+#pragma unroll
+        for (int k = 0; k < X * V; ++k) pb[k] = ld_stream(PBr + (size_t)s * (X * V) + k);
+        M::jac(cc.k, x, vv, A, Bm, Zf);
+      } else {
+#pragma unroll
+        for (int a = 0; a < X; ++a) x[a] = 0.0;
+#pragma unroll
+        for (int a = 0; a < V; ++a) vv[a] = 0.0;
+#pragma unroll
+        for (int k = 0; k < X * V; ++k) pb[k] = 0.0;
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+      }
+      // products of the transition matrices of the later steps (adjoint rows): exclusive prefix products over the lanes
+      double Inc[X * X], E[X * X];
+      dpp_prefix_products<X>(A, Inc, E);
+      // Hessian contraction source of this step, this wavefront's rows
+      double H[NXI];
+      {
+        double Sm[X * NXI];
+#pragma unroll
+        for (int i = 0; i < X * NXI; ++i) Sm[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < RH; ++i) {
+          const bool act = valid && r0 + i >= j && r0 + i < bd.nrows;
+          double Ls[X], dir[NXI];
+#pragma unroll
+          for (int d = 0; d < X; ++d) {
+            double tt = 0.0;
+#pragma unroll
+            for (int a = 0; a < X; ++a) tt += Lam[i * X + a] * E[a * X + d];
+            Ls[d] = tt;
+          }
+#pragma unroll
+          for (int a = 0; a < X; ++a) dir[a] = act ? Xd[(size_t)((r0 + i) * X + a) * TS + s] : 0.0;
+#pragma unroll
+          for (int d = 0; d < V; ++d) {
+            double tt = 0.0;
+#pragma unroll
+            for (int a = 0; a < X; ++a) tt += mlf[i * X + a] * pb[a * V + d];
+            dir[X + d] = tt;
+          }
+#pragma unroll
+          for (int mz = 0; mz < Z; ++mz) dir[X + V + mz] = zdr[i * Z + mz];
+#pragma unroll
+          for (int a = 0; a < X; ++a)
+#pragma unroll
+            for (int m2 = 0; m2 < NXI; ++m2) Sm[a * NXI + m2] += Ls[a] * dir[m2];
+        }
+        M::hess(cc.k, x, vv, Sm, H);
+        if (!valid) {
+#pragma unroll
+          for (int i = 0; i < NXI; ++i) H[i] = 0.0;
+        }
+      }
+      // joint suffix scan for x-bar: x-bar^(l) = x-bar^(l+1) A_l + Hx_l
+      double I2[X * X], gi[X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) I2[i] = A[i];
+#pragma unroll
+      for (int a = 0; a < X; ++a) gi[a] = H[a];
+      dpp_rowaffine_prefix<X>(I2, gi);
+      double xbs[X];  // x-bar at the state after this lane's step
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        double tt = dpp_mov<0x138, 0xf, 0xf>(gi[d], 0.0);  // wave_shr:1: the sources of the later steps
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += xb[a] * E[a * X + d];
+        xbs[d] = tt;
+      }
+      // this wavefront's share of the gradient entries of the tile, summed over the wavefronts in a fixed order
+      double pv[V];
+#pragma unroll
+      for (int d = 0; d < V; ++d) {
+        double tt = H[X + d];
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += Bm[a * V + d] * xbs[a];
+        pv[d] = tt;
+      }
+      if (h > 0) {
+#pragma unroll
+        for (int d = 0; d < V; ++d) sG[buf][h - 1][d][lane] = pv[d];
+      }
+      __syncthreads();
+      if (h == 0 && valid) {
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          double tt = pv[d];
+#pragma unroll
+          for (int k = 0; k < NSPLIT - 1; ++k) tt += sG[buf][k][d][lane];
+          gv[col + d] = tt;
+        }
+      }
+      buf ^= 1;
+#pragma unroll
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt = H[X + V + mz];
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += Zf[a * Z + mz] * xbs[a];
+        zbt[mz] += tt;
+      }
+      // carries
+      double I0[X * X], g0[X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) I0[i] = bcast_lane63(I2[i]);
+#pragma unroll
+      for (int a = 0; a < X; ++a) g0[a] = bcast_lane63(gi[a]);
+      {
+        double nb[X];
+#pragma unroll
+        for (int d = 0; d < X; ++d) {
+          double tt = g0[d];
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt += xb[a] * I0[a * X + d];
+          nb[d] = tt;
+        }
+#pragma unroll
+        for (int d = 0; d < X; ++d) xb[d] = nb[d];
+      }
+#pragma unroll
+      for (int i = 0; i < RH; ++i) {  // Lam <- Lam I0
+        double nl[X];
+#pragma unroll
+        for (int d = 0; d < X; ++d) {
+          double tt = 0.0;
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt += Lam[i * X + a] * I0[a * X + d];
+          nl[d] = tt;
+        }
+#pragma unroll
+        for (int d = 0; d < X; ++d) Lam[i * X + d] = nl[d];
+      }
+    }
+  }
+  // the wavefronts' x-bar at the block start and their z-bar sums, added up by wavefront 0
+#pragma unroll
+  for (int i = 0; i < Z; ++i) {
+    double v = zbt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    zbt[i] = v;
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < X; ++a) sEnd[h][a] = xb[a];
+#pragma unroll
+    for (int i = 0; i < Z; ++i) sEnd[h][X + i] = zbt[i];
+  }
+  __syncthreads();
+  if (h != 0 || lane != 0) return;
+#pragma unroll
+  for (int a = 0; a < X; ++a) {
+    double tt = sEnd[0][a];
+    for (int k = 1; k < NSPLIT; ++k) tt += sEnd[k][a];
+    xb[a] = tt;
+  }
+#pragma unroll
+  for (int i = 0; i < Z; ++i) {
+    double tt = sEnd[0][X + i];
+    for (int k = 1; k < NSPLIT; ++k) tt += sEnd[k][X + i];
+    zbt[i] = tt;
+  }
+  if (bd.first) {
+    double dz[X * Z], dv0[X * V0];
+    M::gx0_jac(dz, dv0);
+    for (int d = 0; d < V0; ++d) {
+      double tt = 0.0;
+      for (int a = 0; a < X; ++a) tt += dv0[a * V0 + d] * xb[a];
+      gv[d] = tt;
+    }
+    for (int mz = 0; mz < Z; ++mz) {
+      double tt = 0.0;
+      for (int a = 0; a < X; ++a) tt += dz[a * Z + mz] * xb[a];
+      zbt[mz] += tt;
+    }
+  }
+  {
     double Gz[Z * Z], gu[U];
     M::gz_jac(q, Gz);
     for (int d = 0; d < Z; ++d) {
