@@ -145,7 +145,8 @@ struct Work {
   int* ok;          // [B] chain still good in this step
   int* status;      // [B]
   int* nstat;       // [B] status of last projection
-  int* n_active;    // [1]
+  int* n_active;    // [4] chains still in the Newton loop after round r, in slot r & 3 (KCheck of round r clears the next
+                    //     slot: no memset between the rounds); per view: [batch | half 0 | half 1] x 4
   unsigned* ticket; // [B] workgroups of a column-max launch that have finished a chain (the last one runs the launch's
                     //     per-chain epilogue: KUpdatePB's fused convergence check)
   const double* zeros;  // [256] zeros (stand-in source for loads of structurally zero Jacobian entries)
@@ -1888,10 +1889,12 @@ struct KCheck {
   int max_iters, B;
   int* iters_dst;  // the step's iteration counter of this retraction direction, or null: a chain's count is added when ITS
                    // loop ends, failed or not (KAddIters: "a chain that failed in this solve still reports its iterations")
+  int slot;        // round & 3: the counter of this round
   CHMC_HD void operator()(int c) const {
+    if (c == 0) w.n_active[(slot + 1) & 3] = 0;  // the next round's counter (its KCheck runs after this launch)
     if (!w.nw[c]) return;
     if (w.nw[c] != 1) {  // its time-parallel forward scan has not settled: not this round's iteration, but not finished
-      atomic_add_i32(w.n_active, 1);
+      atomic_add_i32(w.n_active + slot, 1);
       return;
     }
     const int i = ++w.iters[c];
@@ -1905,7 +1908,7 @@ struct KCheck {
       if (st) w.ok[c] = 0, w.status[c] = st;
       if (iters_dst) iters_dst[c] += i;
     } else {
-      atomic_add_i32(w.n_active, 1);
+      atomic_add_i32(w.n_active + slot, 1);
     }
   }
 };
@@ -1918,7 +1921,7 @@ struct KNewtonBegin {
     w.err[c] = -1.0;
     w.ndq[c] = 0x7ff0000000000000ULL;  // +inf
     w.nstat[c] = 0;
-    if (w.ok[c]) atomic_add_i32(w.n_active, 1);
+    if (c == 0) w.n_active[0] = 0;  // the counter of round 0
   }
 };
 
