@@ -218,6 +218,17 @@ int chmc_neg_log_dens_and_grad(chmc_ctx* ctx, const double* q, int use_gaussian_
 /* The same with q_dev [B][U + V0 + T S V] and grad_dev (may be NULL) in device memory; `value` [B] on the host. */
 int chmc_neg_log_dens_and_grad_device(chmc_ctx* ctx, const void* q_dev, int use_gaussian_splitting, double* value,
                                       void* grad_dev);
+/* The device-resident loop of find_initial_state_by_gradient_descent_noisy_system (sde/mici_extensions.py:1679-1801; its
+ * objective :1706-1737 is the comparator's target for a fixed sigma): one Adam iteration is these two calls.
+ * chmc_adam_objective_device: objective and gradient at u_v_dev [B][U + V0 + T S V] (gradient into grad_dev) and, in one
+ *   read-back, out3 [B][3] = objective, |u_v|^2, 1 if every gradient entry is finite (else 0): what the restart rules
+ *   (:1745-1765) need of the chain.
+ * chmc_adam_update_device: the Adam step (jax.example_libraries.optimizers.adam, :1740) in place on u_v_dev, m_dev, v_dev:
+ *   moments of every chain (non-finite gradient entries count as 0), parameters of chain c moved by
+ *   coef[c][1] * m / (sqrt(v * coef[c][0]) + eps), coef [B][2] on the host = {1 / (1 - b2^t), lr / (1 - b1^t) or 0}. */
+int chmc_adam_objective_device(chmc_ctx* ctx, const void* u_v_dev, void* grad_dev, double* out3);
+int chmc_adam_update_device(chmc_ctx* ctx, void* u_v_dev, void* m_dev, void* v_dev, const void* grad_dev,
+                            const double* coef, double b1, double b2, double eps);
 
 /* Projection solvers (newton != 0: newton_projection :1065-1135 with its host wrapper :1405-1476;
  * newton == 0: quasi_newton_projection :999-1063 / :1323-1402).  Projects the points q [B][Q] onto the manifold

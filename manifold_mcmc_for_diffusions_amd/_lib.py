@@ -73,6 +73,9 @@ SYMBOLS = [
     ("chmc_project_onto_cotangent_space", C.c_int, [C.c_void_p]),
     ("chmc_neg_log_dens_and_grad", C.c_int, [C.c_void_p, dp, C.c_int, dp, dp]),
     ("chmc_neg_log_dens_and_grad_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, dp, C.c_void_p]),
+    ("chmc_adam_objective_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, dp]),
+    ("chmc_adam_update_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, dp, C.c_double,
+                                          C.c_double, C.c_double]),
     ("chmc_hamiltonian", C.c_int, [C.c_void_p, dp]),
     ("chmc_project", C.c_int, [C.c_void_p, C.c_int, dp, dp, C.c_double, C.c_double, C.c_double, C.c_int, dp, dp, ip,
                                dp, dp, ip]),

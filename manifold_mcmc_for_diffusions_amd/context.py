@@ -322,6 +322,20 @@ class ChmcContext:
               "chmc_neg_log_dens_and_grad_device")
         return val
 
+    def adam_objective_device(self, u_v_dev_ptr, grad_dev_ptr):
+        """One read-back per Adam iteration of the initial-state finder: [B, 3] = objective, |u_v|^2, gradient finite."""
+        out = np.empty((self.B, 3))
+        check(self.L.chmc_adam_objective_device(self.h, C.c_void_p(u_v_dev_ptr), C.c_void_p(grad_dev_ptr), ptr(out)),
+              "chmc_adam_objective_device")
+        return out
+
+    def adam_update_device(self, u_v_dev_ptr, m_dev_ptr, v_dev_ptr, grad_dev_ptr, coef, b1=0.9, b2=0.999, eps=1e-8):
+        """Adam step in place on device buffers; coef [B, 2] = 1 / (1 - b2^t), lr / (1 - b1^t) (0: parameters stay)."""
+        coef = as_c(np.asarray(coef, dtype=np.float64).reshape(self.B, 2))
+        check(self.L.chmc_adam_update_device(self.h, C.c_void_p(u_v_dev_ptr), C.c_void_p(m_dev_ptr), C.c_void_p(v_dev_ptr),
+                                             C.c_void_p(grad_dev_ptr), ptr(coef), float(b1), float(b2), float(eps)),
+              "chmc_adam_update_device")
+
     def project(self, q, dt, newton=True, constraint_tol=1e-9, position_tol=1e-8, divergence_tol=1e10, max_iters=50):
         q = self._bq(q, "q")
         dt = as_c(np.broadcast_to(np.asarray(dt, dtype=np.float64), (self.B,)))

@@ -2747,4 +2747,55 @@ struct KHamiltonian {
   }
 };
 
+
+// Adam-based initial states (find_initial_state_by_gradient_descent_noisy_system, sde/mici_extensions.py:1679-1801), the
+// device-resident loop: what the restart rules need of a chain's parameters and gradient (row sums), and the Adam step
+// (jax.example_libraries.optimizers.adam: m <- b1 m + (1 - b1) g, v <- b2 v + (1 - b2) g^2, x <- x - lr m_hat / (sqrt(v_hat) + eps))
+// on the caller's device buffers.  A non-finite gradient entry enters the moments as 0 (its chain is restarted by the host).
+struct KAdamRow {
+  const double* uv;
+  const double* g;
+  int n;
+  CHMC_HD bool active(int) const { return true; }
+  CHMC_HD void operator()(int c, int col, double* acc) const {
+    const size_t i = (size_t)c * n + col;
+    const bool two = col + 1 < n;
+    const double u0 = uv[i], u1 = two ? uv[i + 1] : 0.0, g0 = g[i], g1 = two ? g[i + 1] : 0.0;
+    acc[0] += u0 * u0 + u1 * u1;
+    acc[1] += (g0 - g0 == 0.0 ? 0.0 : 1.0) + (g1 - g1 == 0.0 ? 0.0 : 1.0);  // entries that are not finite
+  }
+};
+struct KAdamStats {
+  const double* part;
+  const double* val;
+  int npart;
+  double* out;  // [B][3]: objective, |u_v|^2, 1 when every gradient entry is finite
+  CHMC_HD void operator()(int c) const {
+    double sq = 0.0, bad = 0.0;
+    for (int j = 0; j < npart; ++j) sq += part[((size_t)c * npart + j) * 2], bad += part[((size_t)c * npart + j) * 2 + 1];
+    out[c * 3] = val[c];
+    out[c * 3 + 1] = sq;
+    out[c * 3 + 2] = bad == 0.0 ? 1.0 : 0.0;
+  }
+};
+struct KAdamUpdate {
+  double* uv;
+  double* m;
+  double* v;
+  const double* g;
+  const double* coef;  // [B][2]: 1 / (1 - b2^t), lr / (1 - b1^t) (0: the chain's parameters stay)
+  int n;
+  double b1, b2, eps;
+  CHMC_HD void operator()(int tid) const {
+    const int c = tid / n;
+    double gg = g[tid];
+    if (!(gg - gg == 0.0)) gg = 0.0;
+    const double mn = b1 * m[tid] + (1.0 - b1) * gg;
+    const double vn = b2 * v[tid] + (1.0 - b2) * gg * gg;
+    m[tid] = mn, v[tid] = vn;
+    const double lr = coef[c * 2 + 1];
+    if (lr != 0.0) uv[tid] -= lr * (mn / (sqrt(vn * coef[c * 2]) + eps));
+  }
+};
+
 }  // namespace chmc

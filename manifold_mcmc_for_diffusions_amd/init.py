@@ -102,8 +102,9 @@ def init_objective_and_grad_device(ctx, u_v_dev_ptr, grad_dev_ptr):
 
 def _adam_on_device(ctx, rng, adam_step_size, max_iters, max_init_tries, threshold, slow_progress_ratio, check_iter,
                     max_num_tries, log):
-    """The finder with (u_v, m, v) and the gradient resident in HBM: per Adam iteration ONE library call (scan + adjoint
-    sweep) and B-sized read-backs; the [B, Q] arrays never cross PCIe.  Same restart rules as the host loop below."""
+    """The finder with (u_v, m, v) and the gradient resident in HBM: per Adam iteration TWO library calls -- objective +
+    gradient + row statistics (scan, adjoint sweep, one [B, 3] read-back), then the Adam step (one kernel, one [B, 2]
+    upload); the [B, Q] arrays never cross PCIe.  Same restart rules as the host loop below."""
     import torch
     dev = _torch_device(ctx)
     B, Q, T = ctx.B, ctx.Q, ctx.T
@@ -117,13 +118,10 @@ def _adam_on_device(ctx, rng, adam_step_size, max_iters, max_init_tries, thresho
     prev = np.full(B, np.inf)
     it_in_try = np.zeros(B, dtype=np.int64)
     b1, b2, eps = 0.9, 0.999, 1e-8                         # jax.example_libraries.optimizers.adam defaults
-    col = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev).reshape(B, 1)  # noqa: E731
     for _ in range(max_iters * max_num_tries):
         torch.cuda.synchronize(dev)                        # (the library enqueues on its own stream)
-        val = init_objective_and_grad_device(ctx, u_v.data_ptr(), g.data_ptr())
-        sq = torch.linalg.vecdot(u_v, u_v)
-        gfin = torch.isfinite(g.sum(1))                    # (a non-finite entry makes the row sum non-finite)
-        sq, gfin = sq.cpu().numpy(), gfin.cpu().numpy()
+        st = ctx.adam_objective_device(u_v.data_ptr(), g.data_ptr())   # objective, |u_v|^2, gradient finite: one read-back
+        val, sq, gfin = st[:, 0], st[:, 1], st[:, 2] != 0.0
         msq = 2.0 * (val - T * np.log(sigma) - 0.5 * sq) / T   # mean squared residual
         newly = ~done & np.isfinite(msq) & (msq < threshold)
         done |= newly
@@ -140,19 +138,17 @@ def _adam_on_device(ctx, rng, adam_step_size, max_iters, max_init_tries, thresho
             idx = torch.from_numpy(np.flatnonzero(restart)).to(dev)
             u_v[idx] = torch.from_numpy(rng.standard_normal((int(restart.sum()), nuv))).to(dev)
             m[idx], v[idx] = 0.0, 0.0
+            g[idx] = 0.0                                   # (a restarted chain's moments start from zero at its next gradient)
             t_adam[restart], it_in_try[restart], prev[restart] = 0.0, 0, np.inf
             tries[restart] += 1
+            torch.cuda.synchronize(dev)
         step = ~done & ~restart
         t_adam[step] += 1
         # Adam moments in place for every chain (a finished chain's moments are never used again, a restarted chain's were
-        # zeroed above and its non-finite gradient is dropped); only the parameter update is masked
-        torch.nan_to_num_(g, nan=0.0, posinf=0.0, neginf=0.0)
-        m.mul_(b1).add_(g, alpha=1 - b1)
-        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        # zeroed above and its gradient dropped); only the parameter update is masked: one library kernel
         tt = np.maximum(t_adam, 1.0)
-        upd = torch.sqrt(v * col(1.0 / (1 - b2 ** tt))).add_(eps)
-        torch.div(m, upd, out=upd)
-        u_v.sub_(upd.mul_(col(np.where(step, adam_step_size / (1 - b1 ** tt), 0.0))))
+        coef = np.stack([1.0 / (1 - b2 ** tt), np.where(step, adam_step_size / (1 - b1 ** tt), 0.0)], 1)
+        ctx.adam_update_device(u_v.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), coef, b1, b2, eps)
         it_in_try[step] += 1
         if log is not None and int(it_in_try.max()) % check_iter == 0:
             log(f"  adam (device): {int(done.sum())} of {B} chains below the threshold, median mean r^2 {np.median(msq):.3g}")

@@ -191,4 +191,34 @@ def test_adam_finder_objective_gradient_and_device_loop_against_the_oracle():
     # the iteration at which a chain crosses the threshold)
     assert (np.mean(q2[:, -T:] ** 2, 1) < 1.0).all() and np.abs(ctx.constr()).max() < 1e-9
     assert abs(int(tries1.sum()) - int(tries2.sum())) <= B
+    # (iii) the two library calls of a device-resident iteration against NumPy: the row statistics of the restart rules and
+    # the Adam step (jax.example_libraries.optimizers.adam), with non-finite gradient entries and a masked chain
+    gh = g.copy()
+    gh[2, 5], gh[4, 0] = np.nan, np.inf
+    gd.copy_(torch.from_numpy(gh))
+    st = ctx.adam_objective_device(ud.data_ptr(), gd.data_ptr())       # (rewrites gd with the gradient at ud)
+    np.testing.assert_allclose(st[:, 0], val, rtol=1e-14)
+    np.testing.assert_allclose(st[:, 1], np.sum(u_v ** 2, 1), rtol=1e-13)
+    assert (st[:, 2] == 1.0).all()
+    gd.copy_(torch.from_numpy(gh))
+    rng2 = np.random.default_rng(5)
+    m0, v0 = rng2.standard_normal((B, nuv)), rng2.random((B, nuv))
+    md, vd = torch.from_numpy(m0).to(dev), torch.from_numpy(v0).to(dev)
+    tt = rng2.integers(1, 40, B).astype(float)
+    lr = np.where(np.arange(B) == 3, 0.0, 0.1 / (1 - 0.9 ** tt))      # chain 3: a finished chain, parameters stay
+    coef = np.stack([1.0 / (1 - 0.999 ** tt), lr], 1)
+    torch.cuda.synchronize()
+    ctx.adam_update_device(ud.data_ptr(), md.data_ptr(), vd.data_ptr(), gd.data_ptr(), coef, 0.9, 0.999, 1e-8)
+    g0 = np.where(np.isfinite(gh), gh, 0.0)
+    m1, v1 = 0.9 * m0 + (1 - 0.9) * g0, 0.999 * v0 + (1 - 0.999) * g0 ** 2
+    u1 = u_v - lr[:, None] * m1 / (np.sqrt(v1 * coef[:, :1]) + 1e-8)
+    np.testing.assert_allclose(md.cpu().numpy(), m1, rtol=1e-13, atol=1e-15)   # (fused multiply-adds on the device)
+    np.testing.assert_allclose(vd.cpu().numpy(), v1, rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(ud.cpu().numpy(), u1, rtol=1e-13, atol=1e-15)
+    assert np.array_equal(ud.cpu().numpy()[3], u_v[3])
+    ud[5] *= 1e120                                          # an overflowing chain: flagged by its value or its gradient
+    torch.cuda.synchronize()
+    st = ctx.adam_objective_device(ud.data_ptr(), gd.data_ptr())
+    assert (not np.isfinite(st[5, 0])) or st[5, 2] == 0.0
+    assert (st[np.arange(B) != 5, 2] == 1.0).all()
     ctx.close()
