@@ -720,6 +720,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
 // STATE (with PBJ): the same sweep as the STATE EVALUATION of slot `which` (k_rev_wave<MODE 0> at a third of its
 // registers): the Gram block is that of the point itself (X x X running sum of T T^T, own frames), the compact rows PB / LF
 // and the v_0 columns of the rows are written, dc/du rows go to the slot and dc/dz rows to work.zbP.
+#define CHMC_IVL_N(X, Z) (2 * (X) * (X) + (X) * (Z))  // per-interval sums Ss, Ws, Pt (k_newton_ivl below)
 template <class M, int RM, bool PBJ = false, bool STATE = false>
 __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVES_PB : CHMC_LEAN_WAVES)
     k_newton_lean(Sys sy, Slots sl, Work w, int which, int qsel) {
@@ -798,6 +799,19 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
       Wacc[i] = 0.0;
     }
     lds_sync();
+    if constexpr (STATE) {
+      // the swept interval's sums for the forward grad-log-det sweep (k_gld_fwd_qx): Ss = sum T T^T, Ws = sum PE Zf, Pt,
+      // in k_newton_ivl's layout
+      if (jprev < bd.nobs && w.ivl) {
+        double* iv = w.ivl + (cb * sy.NOBS + jprev) * CHMC_IVL_N(X, Z);
+        if (lane < X * X) iv[lane] = Ss[lane];
+        if (lane < X * Z) iv[X * X + lane] = Ws[lane];
+        if (lane == 0) {
+#pragma unroll
+          for (int i = 0; i < X * X; ++i) iv[X * X + X * Z + i] = Pf[i];
+        }
+      }
+    }
     double nl = 0.0;  // entry `lane` of the rows at the start of the swept interval, LamF Pf
     if (lane < RM * X) {
       const int i = lane / X, d = lane - i * X;
@@ -1057,7 +1071,6 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
 //            Gram += LamF[m] Ss[m] LFprev[m]^T;  dc/dz rows += LamF[m] Ws[m] -- and finishes as k_newton_lean does
 //            (v_0 columns, observation-noise diagonal, identity padding, dc/du rows through generate_z').
 // Any RM <= 16: no per-lane array is indexed by the row.
-#define CHMC_IVL_N(X, Z) (2 * (X) * (X) + (X) * (Z))
 // (166 VGPRs for FitzHugh-Nagumo: three wavefronts per SIMD at run time; capped at 128 for four it spills, 3x slower)
 #ifndef CHMC_IVL_WAVES
 #define CHMC_IVL_WAVES 2
@@ -2289,6 +2302,219 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
         if (r0 + i == j)
 #pragma unroll
           for (int a = 0; a < X; ++a) w.gxdt[(cb * RM + j) * X + a] = xdc[i * X + a];
+    }
+  }
+}
+
+// The forward sweep in the form the row-free backward sweep needs (Qx_s = sum_i LF[m][i]^T xd_i(s)^T, X x X per step) WITHOUT
+// the RM row tangents.  Inside observation interval m the frames are constant, so Qx obeys the tangents' own recursion with
+// X pseudo-rows instead of RM rows:
+//     Qx_{s+1}[r] = A_s Qx_s[r] + B_s (PB_s^T C1_m[r]) + Zf_s C2_m[r],   C1_m = LF[m]^T MLF[m] (X x X),  C2_m = LF[m]^T zd (X x Z),
+// started at the interval's first step from Q0_m = LF[m]^T xd(t_m).  The row tangents are only needed at the interval
+// boundaries, where they follow from the state sweep's interval sums (k_newton_lean<.., STATE> leaves Ss, Ws, Pt in work.ivl):
+//     xd_i(t_{m+1}) = Pt_m xd_i(t_m) + Ss_m MLF[m][i]^T + Ws_m zd_i
+// -- a prologue of nobs tiny steps per block (entries over the lanes, everything RM-sized in LDS).  The affine scan of a
+// tile then carries X instead of RM vectors (FitzHugh-Nagumo: 2 instead of 7).  Also writes the rows' terminal tangents
+// (work.gxdt) for the backward sweep.  Blocks of at most 8 rows on the compact rows.
+template <class M, int RM>
+__global__ void __launch_bounds__(256) k_gld_fwd_qx(Sys sy, Slots sl, Work w, int which) {
+  constexpr int X = M::X, V = M::V, Z = M::Z, V0 = M::V0;
+  constexpr int NI = CHMC_IVL_N(X, Z), NC = X * X + X * Z + X * X;  // per interval: C1, C2, Q0
+  static_assert(RM <= 8, "blocks of at most 8 rows (at most RM observation intervals per block)");
+  __shared__ double sm[4][RM * RM + RM * Z + 2 * RM * X + RM * NC + NI];
+  const int lane = threadIdx.x & 63;
+  const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wid = blockIdx.x * (blockDim.x >> 6) + wv_;
+  if (wid >= sy.B * sy.K) return;
+  const int cbi = sy.order[wid];  // work order: longest blocks first
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (!w.ok[c]) return;
+  const BlockDesc bd = sy.blk[b];
+  const int s_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int S = sy.S, NV = sy.NV;
+  const size_t TS = (size_t)sy.T * S;
+  const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* Jv = pick(sl.Jv, s_) + (size_t)c * RM * NV;
+  const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  double* Xd = w.Xd + (size_t)c * RM * X * TS + bd.step0;
+  double* Mb = sm[wv_];
+  double* zd = Mb + RM * RM;
+  double* MLFs = zd + RM * Z;
+  double* xds = MLFs + RM * X;   // row tangents at the start of the current interval
+  double* Cs = xds + RM * X;     // [nobs][C1 | C2 | Q0]
+  double* Iv = Cs + RM * NC;     // the interval's sums Ss | Ws | Pt
+  const double* PBr = pick(sl.PB, s_) + ((size_t)c * TS + bd.step0) * (X * V);
+  const double* LFr = pick(sl.LF, s_) + cb * sy.NOBS * RM * X;
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int i = lane; i < RM * RM; i += 64) Mb[i] = w.gMb[cb * RM * RM + i];
+  for (int i = lane; i < RM * Z; i += 64) zd[i] = w.gzd[cb * RM * Z + i];
+  lds_sync();
+  // ---- prologue: row tangents at the interval boundaries, and C1, C2, Q0 of every interval
+  if (lane < RM * X) {
+    const int i = lane / X, a = lane - i * X;
+    double t = 0.0;
+    if (bd.first) {
+      double dz[X * Z], dv0[X * V0];
+      M::gx0_jac(dz, dv0);
+      for (int mz = 0; mz < Z; ++mz) {
+        double dzs = 0.0;
+#pragma unroll
+        for (int e2 = 0; e2 < X * Z; ++e2) dzs = e2 == a * Z + mz ? dz[e2] : dzs;
+        t += dzs * zd[i * Z + mz];
+      }
+      for (int d = 0; d < V0; ++d) {
+        double wv = 0.0, dvs = 0.0;
+        for (int jj = 0; jj < RM; ++jj) wv += Mb[i * RM + jj] * Jv[(size_t)jj * NV + d];
+#pragma unroll
+        for (int e2 = 0; e2 < X * V0; ++e2) dvs = e2 == a * V0 + d ? dv0[e2] : dvs;
+        t += dvs * wv;
+      }
+    }
+    xds[lane] = t;
+  }
+  for (int j = 0; j < bd.nobs; ++j) {
+    lds_sync();
+    if (lane < RM * X) {  // MLF[j] = (G^-1)_bb LF[j]
+      const int i = lane / X, a = lane - i * X;
+      double t = 0.0;
+      for (int jj = 0; jj < RM; ++jj) t += Mb[i * RM + jj] * LFr[((size_t)j * RM + jj) * X + a];
+      MLFs[lane] = t;
+    }
+    for (int e2 = lane; e2 < NI; e2 += 64) Iv[e2] = w.ivl[(cb * sy.NOBS + j) * NI + e2];
+    lds_sync();
+    double* Cj = Cs + j * NC;
+    if (lane < X * X) {  // C1[a1][a] = sum_i LF[j][i][a1] MLF[j][i][a];  Q0[a1][a2] = sum_i LF[j][i][a1] xd_i[a2]
+      const int a1 = lane / X, a2 = lane - a1 * X;
+      double c1 = 0.0, q0 = 0.0;
+      for (int i = 0; i < RM; ++i) {
+        const double lf = LFr[((size_t)j * RM + i) * X + a1];
+        c1 += lf * MLFs[i * X + a2];
+        q0 += lf * xds[i * X + a2];
+      }
+      Cj[lane] = c1;
+      Cj[X * X + X * Z + lane] = q0;
+    }
+    if (lane < X * Z) {  // C2[a1][mz] = sum_i LF[j][i][a1] zd[i][mz]
+      const int a1 = lane / Z, mz = lane - a1 * Z;
+      double c2 = 0.0;
+      for (int i = 0; i < RM; ++i) c2 += LFr[((size_t)j * RM + i) * X + a1] * zd[i * Z + mz];
+      Cj[X * X + lane] = c2;
+    }
+    double nx = 0.0;  // row tangent at the interval's end: Pt xd_i + Ss MLF[j][i]^T + Ws zd_i
+    if (lane < RM * X) {
+      const int i = lane / X, a = lane - i * X;
+#pragma unroll
+      for (int d = 0; d < X; ++d) nx += Iv[X * X + X * Z + a * X + d] * xds[i * X + d] + Iv[a * X + d] * MLFs[i * X + d];
+      for (int mz = 0; mz < Z; ++mz) nx += Iv[X * X + a * Z + mz] * zd[i * Z + mz];
+    }
+    lds_sync();
+    if (lane < RM * X) xds[lane] = nx;
+    {
+      const double tv = __shfl(nx, (j * X + lane) & 63, 64);  // (every lane takes part: the sources must be active)
+      if (j < bd.ny && lane < X) w.gxdt[(cb * RM + j) * X + lane] = tv;  // terminal tangent of row j
+    }
+  }
+  lds_sync();
+  // ---- the sweep: X pseudo-rows per interval
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  const int ntile = (S + 63) >> 6;
+  for (int j = 0; j < bd.nobs; ++j) {
+    const double* Cj = Cs + j * NC;
+    double c1[X * X], c2[X * Z], xdc[X * X];
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) c1[i] = Cj[i], xdc[i] = Cj[X * X + X * Z + i];
+#pragma unroll
+    for (int i = 0; i < X * Z; ++i) c2[i] = Cj[X * X + i];
+    for (int t = 0; t < ntile; ++t) {
+      const int off = (t << 6) + lane;
+      const bool valid = off < S;
+      const int s = j * S + off;
+      double P[X * X], e[X * X];
+      {
+        double A[X * X], Bm[X * V], Zf[X * Z], jp[X * V];
+        if (valid) {
+          double x[X], vv[V];
+#pragma unroll
+          for (int a = 0; a < X; ++a) x[a] = ld_stream(traj + (size_t)s * X + a);
+#pragma unroll
+          for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
+          M::jac(cc.k, x, vv, A, Bm, Zf);
+#pragma unroll
+          for (int k = 0; k < X * V; ++k) jp[k] = ld_stream(PBr + (size_t)s * (X * V) + k);
+        } else {
+#pragma unroll
+          for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+          for (int i = 0; i < X * V; ++i) Bm[i] = 0.0, jp[i] = 0.0;
+#pragma unroll
+          for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) P[i] = A[i];
+#pragma unroll
+        for (int r = 0; r < X; ++r) {
+          double wv[V];
+#pragma unroll
+          for (int d = 0; d < V; ++d) {
+            double tt = 0.0;
+#pragma unroll
+            for (int a = 0; a < X; ++a) tt += c1[r * X + a] * jp[a * V + d];
+            wv[d] = tt;
+          }
+#pragma unroll
+          for (int a = 0; a < X; ++a) {
+            double tt = 0.0;
+#pragma unroll
+            for (int d = 0; d < V; ++d) tt += Bm[a * V + d] * wv[d];
+#pragma unroll
+            for (int mz = 0; mz < Z; ++mz) tt += Zf[a * Z + mz] * c2[r * Z + mz];
+            e[r * X + a] = tt;
+          }
+        }
+      }
+      dpp_affine_prefix<X, X>(P, e);
+      {
+        double xs[X * X], Pex[X * X];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) xs[i] = dpp_mov<0x138, 0xf, 0xf>(e[i], 0.0);  // wave_shr:1
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) Pex[i] = dpp_mov<0x138, 0xf, 0xf>(P[i], (i / X == i % X) ? 1.0 : 0.0);
+#pragma unroll
+        for (int r = 0; r < X; ++r)
+#pragma unroll
+          for (int a = 0; a < X; ++a) {
+            double tt = xs[r * X + a];
+#pragma unroll
+            for (int d = 0; d < X; ++d) tt += Pex[a * X + d] * xdc[r * X + d];
+            xs[r * X + a] = tt;
+          }
+        if (valid) {
+#pragma unroll
+          for (int i = 0; i < X * X; ++i) st_async(Xd + (size_t)i * TS + s, xs[i]);
+        }
+      }
+      {
+        double P6[X * X], nx[X * X];
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) P6[i] = bcast_lane63(P[i]);
+#pragma unroll
+        for (int r = 0; r < X; ++r)
+#pragma unroll
+          for (int a = 0; a < X; ++a) {
+            double tt = bcast_lane63(e[r * X + a]);
+#pragma unroll
+            for (int d = 0; d < X; ++d) tt += P6[a * X + d] * xdc[r * X + d];
+            nx[r * X + a] = tt;
+          }
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) xdc[i] = nx[i];
+      }
     }
   }
 }
