@@ -147,6 +147,8 @@ struct Work {
   int* nstat;       // [B] status of last projection
   int* n_active;    // [4] chains still in the Newton loop after round r, in slot r & 3 (KCheck of round r clears the next
                     //     slot: no memset between the rounds); per view: [batch | half 0 | half 1] x 4
+  double* gcq;      // [B][Kmax][NOBS][2 X X + X Z] interval-parallel grad-log-det: C1 | C2 | Q0 of every interval (few long blocks)
+  double* gbw;      // [B][Kmax][NOBS][X + 2 Z]     its backward sweep: x-bar handed on | z-bar sums of the two phases
   unsigned* ticket; // [B] workgroups of a column-max launch that have finished a chain (the last one runs the launch's
                     //     per-chain epilogue: KUpdatePB's fused convergence check)
   const double* zeros;  // [256] zeros (stand-in source for loads of structurally zero Jacobian entries)

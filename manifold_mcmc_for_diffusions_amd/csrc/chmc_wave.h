@@ -2064,14 +2064,10 @@ __global__ void __launch_bounds__(256) k_jw_pb(Sys sy, Slots sl, Work w, int whi
 #ifndef CHMC_GLD_FWD_DPP_MAXROWS
 #define CHMC_GLD_FWD_DPP_MAXROWS 16
 #endif
-// NSPLIT: the rows of a block dealt out to NSPLIT wavefronts (the tangents of different rows are independent recursions
-// over the same transition matrices): one-block-per-chain layouts leave three quarters of the chip's SIMDs empty at one
-// wavefront per block, and the affine scan -- RH X vectors per lane -- is most of a tile's work.
-template <class M, int RM, bool PBJ = false, bool QX = false, int NSPLIT = 1>
+template <class M, int RM, bool PBJ = false, bool QX = false>
 __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, int which) {
   constexpr int X = M::X, V = M::V, Z = M::Z, V0 = M::V0;
-  constexpr int RH = RM / NSPLIT;  // rows of this wavefront
-  static_assert(RM % NSPLIT == 0 && (NSPLIT == 1 || !QX), "row split: equal shares, tangents stored per row");
+  constexpr int RH = RM, NSPLIT = 1;  // (a row split over NSPLIT wavefronts was built and superseded by k_gld_fwd_ivl: DESIGN.md)
   constexpr int URM = 64;  // (the forward sweep is correct fully unrolled at 16 rows as well; the backward sweep is not, see there)
   __shared__ double sm[4][RM * RM + RM * Z + (PBJ ? RM * X : 0)];
   const int lane = threadIdx.x & 63;
@@ -2320,7 +2316,7 @@ template <class M, int RM>
 __global__ void __launch_bounds__(256) k_gld_fwd_qx(Sys sy, Slots sl, Work w, int which) {
   constexpr int X = M::X, V = M::V, Z = M::Z, V0 = M::V0;
   constexpr int NI = CHMC_IVL_N(X, Z), NC = X * X + X * Z + X * X;  // per interval: C1, C2, Q0
-  static_assert(RM <= 8, "blocks of at most 8 rows (at most RM observation intervals per block)");
+  // (a block has at most RM observation intervals: every observation contributes a row)
   __shared__ double sm[4][RM * RM + RM * Z + 2 * RM * X + RM * NC + NI];
   const int lane = threadIdx.x & 63;
   const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2809,7 +2805,6 @@ __global__ void __launch_bounds__(PBJ && CHMC_GLD_BWD_WAVES > 1 ? 64 : 256, PBJ 
 template <class M, int RM>
 __global__ void __launch_bounds__(64, CHMC_GLD_LEAN_WAVES) k_gld_bwd_lean(Sys sy, Slots sl, Work w, int which) {
   constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0, NXI = M::NXI;
-  static_assert(RM <= 8, "blocks of at most 8 rows");
   __shared__ double Mb[RM * RM], zd[RM * Z], LFs[RM * X], MLFs[RM * X], CQ[X * X + X * Z];
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x;
@@ -3050,6 +3045,533 @@ __global__ void __launch_bounds__(64, CHMC_GLD_LEAN_WAVES) k_gld_bwd_lean(Sys sy
 
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// Grad-log-det for FEW LONG blocks (the SIR single-block layout), every observation interval on its own wavefront.  With
+// the row-free forms (k_gld_fwd_qx, k_gld_bwd_lean) a step only sees per-interval X x X / X x Z matrices, and what crosses
+// an interval boundary is small and follows from the state sweep's interval sums (work.ivl: Ss, Ws, Pt):
+//   k_gld_ivl_prologue  wave per (chain, block): the row tangents at the interval boundaries (as k_gld_fwd_qx's prologue),
+//                       C1 = LF^T MLF, C2 = LF^T zd, Q0 = LF^T xd(t_m) of every interval -> work.gcq, terminal tangents -> gxdt
+//   k_gld_fwd_ivl       wave per (chain, block, interval): the pseudo-row sweep of that interval from Q0 -> Qx
+//   k_gld_bwd_ivl_a     wave per (chain, block, interval): the backward sweep of the interval with NO incoming x-bar (its own
+//                       observation's Hessian term included): gradient entries, z-bar sum and the x-bar it hands on -> work.gbw
+//   k_gld_bwd_ivl_b     wave per (chain, block, interval): x-bar arriving at the interval's end = the later intervals' hand-ons
+//                       carried through their transition products (x-bar is an affine recursion); its contribution to the
+//                       interval's gradient entries and z-bar needs the step Jacobians and prefix products only (no Hessian)
+//   KGldIvlFinish       per (chain, block): sums, v_0 columns, dc/dz terms, work.gup (the tail of k_gld_bwd_lean)
+#define CHMC_GCQ_N(X, Z) (2 * (X) * (X) + (X) * (Z))  // per interval: C1 | C2 | Q0
+#define CHMC_GBW_N(X, Z) ((X) + 2 * (Z))               // per interval: x-bar handed on | z-bar (phase a) | z-bar (phase b)
+template <class M, int RM>
+__global__ void __launch_bounds__(256) k_gld_ivl_prologue(Sys sy, Slots sl, Work w, int which) {
+  constexpr int X = M::X, Z = M::Z, V0 = M::V0;
+  constexpr int NI = CHMC_IVL_N(X, Z), NC = CHMC_GCQ_N(X, Z);
+  __shared__ double sm[4][RM * RM + RM * Z + 2 * RM * X + NI];
+  const int lane = threadIdx.x & 63;
+  const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wid = blockIdx.x * (blockDim.x >> 6) + wv_;
+  if (wid >= sy.B * sy.K) return;
+  const int cbi = sy.order[wid];
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (!w.ok[c]) return;
+  const BlockDesc bd = sy.blk[b];
+  const int s_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int NV = sy.NV;
+  const double* Jv = pick(sl.Jv, s_) + (size_t)c * RM * NV;
+  const double* LFr = pick(sl.LF, s_) + cb * sy.NOBS * RM * X;
+  double* Mb = sm[wv_];
+  double* zd = Mb + RM * RM;
+  double* MLFs = zd + RM * Z;
+  double* xds = MLFs + RM * X;
+  double* Iv = xds + RM * X;
+  auto lds_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  };
+  for (int i = lane; i < RM * RM; i += 64) Mb[i] = w.gMb[cb * RM * RM + i];
+  for (int i = lane; i < RM * Z; i += 64) zd[i] = w.gzd[cb * RM * Z + i];
+  lds_sync();
+  if (lane < RM * X) {
+    const int i = lane / X, a = lane - i * X;
+    double t = 0.0;
+    if (bd.first) {
+      double dz[X * Z], dv0[X * V0];
+      M::gx0_jac(dz, dv0);
+      for (int mz = 0; mz < Z; ++mz) {
+        double dzs = 0.0;
+#pragma unroll
+        for (int e2 = 0; e2 < X * Z; ++e2) dzs = e2 == a * Z + mz ? dz[e2] : dzs;
+        t += dzs * zd[i * Z + mz];
+      }
+      for (int d = 0; d < V0; ++d) {
+        double wv = 0.0, dvs = 0.0;
+        for (int jj = 0; jj < RM; ++jj) wv += Mb[i * RM + jj] * Jv[(size_t)jj * NV + d];
+#pragma unroll
+        for (int e2 = 0; e2 < X * V0; ++e2) dvs = e2 == a * V0 + d ? dv0[e2] : dvs;
+        t += dvs * wv;
+      }
+    }
+    xds[lane] = t;
+  }
+  for (int j = 0; j < bd.nobs; ++j) {
+    lds_sync();
+    if (lane < RM * X) {
+      const int i = lane / X, a = lane - i * X;
+      double t = 0.0;
+      for (int jj = 0; jj < RM; ++jj) t += Mb[i * RM + jj] * LFr[((size_t)j * RM + jj) * X + a];
+      MLFs[lane] = t;
+    }
+    for (int e2 = lane; e2 < NI; e2 += 64) Iv[e2] = w.ivl[(cb * sy.NOBS + j) * NI + e2];
+    lds_sync();
+    double* Cj = w.gcq + (cb * sy.NOBS + j) * NC;
+    if (lane < X * X) {
+      const int a1 = lane / X, a2 = lane - a1 * X;
+      double c1 = 0.0, q0 = 0.0;
+      for (int i = 0; i < RM; ++i) {
+        const double lf = LFr[((size_t)j * RM + i) * X + a1];
+        c1 += lf * MLFs[i * X + a2];
+        q0 += lf * xds[i * X + a2];
+      }
+      Cj[lane] = c1;
+      Cj[X * X + X * Z + lane] = q0;
+    }
+    if (lane < X * Z) {
+      const int a1 = lane / Z, mz = lane - a1 * Z;
+      double c2 = 0.0;
+      for (int i = 0; i < RM; ++i) c2 += LFr[((size_t)j * RM + i) * X + a1] * zd[i * Z + mz];
+      Cj[X * X + lane] = c2;
+    }
+    double nx = 0.0;
+    if (lane < RM * X) {
+      const int i = lane / X, a = lane - i * X;
+#pragma unroll
+      for (int d = 0; d < X; ++d) nx += Iv[X * X + X * Z + a * X + d] * xds[i * X + d] + Iv[a * X + d] * MLFs[i * X + d];
+      for (int mz = 0; mz < Z; ++mz) nx += Iv[X * X + a * Z + mz] * zd[i * Z + mz];
+    }
+    lds_sync();
+    if (lane < RM * X) xds[lane] = nx;
+    {
+      const double tv = __shfl(nx, (j * X + lane) & 63, 64);
+      if (j < bd.ny && lane < X) w.gxdt[(cb * RM + j) * X + lane] = tv;
+    }
+  }
+}
+
+// (wid -> (chain, block, interval); false when the wavefront has nothing to do)
+__device__ inline bool gld_ivl_ids(const Sys& sy, const Work& w, int wid, int& c, int& b, int& j) {
+  if (wid >= sy.B * sy.K * sy.NOBS) return false;
+  j = wid % sy.NOBS;
+  const int cbi = sy.order[wid / sy.NOBS];
+  c = cbi / sy.K, b = cbi - c * sy.K;
+  return w.ok[c] != 0 && j < sy.blk[b].nobs;
+}
+
+template <class M, int RM>
+__global__ void __launch_bounds__(256) k_gld_fwd_ivl(Sys sy, Slots sl, Work w, int which) {
+  constexpr int X = M::X, V = M::V, Z = M::Z;
+  constexpr int NC = CHMC_GCQ_N(X, Z);
+  const int lane = threadIdx.x & 63;
+  const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int c, b, j;
+  if (!gld_ivl_ids(sy, w, blockIdx.x * (blockDim.x >> 6) + wv_, c, b, j)) return;
+  const BlockDesc bd = sy.blk[b];
+  const int s_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int S = sy.S;
+  const size_t TS = (size_t)sy.T * S;
+  const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  double* Xd = w.Xd + (size_t)c * RM * X * TS + bd.step0;
+  const double* PBr = pick(sl.PB, s_) + ((size_t)c * TS + bd.step0) * (X * V);
+  const double* Cj = w.gcq + (cb * sy.NOBS + j) * NC;
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  double c1[X * X], c2[X * Z], xdc[X * X];
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) c1[i] = Cj[i], xdc[i] = Cj[X * X + X * Z + i];
+#pragma unroll
+  for (int i = 0; i < X * Z; ++i) c2[i] = Cj[X * X + i];
+  const int ntile = (S + 63) >> 6;
+  for (int t = 0; t < ntile; ++t) {
+    const int off = (t << 6) + lane;
+    const bool valid = off < S;
+    const int s = j * S + off;
+    double P[X * X], e[X * X];
+    {
+      double A[X * X], Bm[X * V], Zf[X * Z], jp[X * V];
+      if (valid) {
+        double x[X], vv[V];
+#pragma unroll
+        for (int a = 0; a < X; ++a) x[a] = ld_stream(traj + (size_t)s * X + a);
+#pragma unroll
+        for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
+        M::jac(cc.k, x, vv, A, Bm, Zf);
+#pragma unroll
+        for (int k = 0; k < X * V; ++k) jp[k] = ld_stream(PBr + (size_t)s * (X * V) + k);
+      } else {
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+        for (int i = 0; i < X * V; ++i) Bm[i] = 0.0, jp[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) P[i] = A[i];
+#pragma unroll
+      for (int r = 0; r < X; ++r) {
+        double wv[V];
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          double tt = 0.0;
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt += c1[r * X + a] * jp[a * V + d];
+          wv[d] = tt;
+        }
+#pragma unroll
+        for (int a = 0; a < X; ++a) {
+          double tt = 0.0;
+#pragma unroll
+          for (int d = 0; d < V; ++d) tt += Bm[a * V + d] * wv[d];
+#pragma unroll
+          for (int mz = 0; mz < Z; ++mz) tt += Zf[a * Z + mz] * c2[r * Z + mz];
+          e[r * X + a] = tt;
+        }
+      }
+    }
+    dpp_affine_prefix<X, X>(P, e);
+    {
+      double xs[X * X], Pex[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) xs[i] = dpp_mov<0x138, 0xf, 0xf>(e[i], 0.0);
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Pex[i] = dpp_mov<0x138, 0xf, 0xf>(P[i], (i / X == i % X) ? 1.0 : 0.0);
+#pragma unroll
+      for (int r = 0; r < X; ++r)
+#pragma unroll
+        for (int a = 0; a < X; ++a) {
+          double tt = xs[r * X + a];
+#pragma unroll
+          for (int d = 0; d < X; ++d) tt += Pex[a * X + d] * xdc[r * X + d];
+          xs[r * X + a] = tt;
+        }
+      if (valid) {
+#pragma unroll
+        for (int i = 0; i < X * X; ++i) st_async(Xd + (size_t)i * TS + s, xs[i]);
+      }
+    }
+    {
+      double P6[X * X], nx[X * X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) P6[i] = bcast_lane63(P[i]);
+#pragma unroll
+      for (int r = 0; r < X; ++r)
+#pragma unroll
+        for (int a = 0; a < X; ++a) {
+          double tt = bcast_lane63(e[r * X + a]);
+#pragma unroll
+          for (int d = 0; d < X; ++d) tt += P6[a * X + d] * xdc[r * X + d];
+          nx[r * X + a] = tt;
+        }
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) xdc[i] = nx[i];
+    }
+  }
+}
+
+// PHASE 0: everything (Hessian contraction source, gradient entries without the incoming x-bar); PHASE 1: the incoming
+// x-bar's contribution only
+template <class M, int RM, int PHASE>
+__global__ void __launch_bounds__(256) k_gld_bwd_ivl(Sys sy, Slots sl, Work w, int which) {
+  constexpr int X = M::X, V = M::V, Z = M::Z, NXI = M::NXI;
+  constexpr int NI = CHMC_IVL_N(X, Z), NC = CHMC_GCQ_N(X, Z), NB = CHMC_GBW_N(X, Z);
+  const int lane = threadIdx.x & 63;
+  const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int c, b, j;
+  if (!gld_ivl_ids(sy, w, blockIdx.x * (blockDim.x >> 6) + wv_, c, b, j)) return;
+  const BlockDesc bd = sy.blk[b];
+  const int s_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const int S = sy.S;
+  const size_t TS = (size_t)sy.T * S;
+  const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
+  const double* Xq = w.Xd + (size_t)c * RM * X * TS + bd.step0;  // Qx, component-major: [X X][T S]
+  double* gv = pick(sl.grad, s_) + (size_t)c * sy.Q + sy.U;
+  const double* PBr = pick(sl.PB, s_) + ((size_t)c * TS + bd.step0) * (X * V);
+  const double* Cj = w.gcq + (cb * sy.NOBS + j) * NC;
+  double* gb = w.gbw + (cb * sy.NOBS + j) * NB;
+  ChainConsts<M> cc;
+  cc.init(q, sy.dl);
+  double xb[X], zbt[Z], Pf[X * X], Cm[X * X], Qz[X * Z];
+#pragma unroll
+  for (int i = 0; i < X; ++i) xb[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < Z; ++i) zbt[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < X * X; ++i) Cm[i] = Cj[i], Pf[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+  for (int i = 0; i < X * Z; ++i) Qz[i] = Cj[X * X + i];
+  if (PHASE == 0) {
+    if (j < bd.ny) {  // the Hessian term of the observation at the interval's end
+      double hv[X], xt[X];
+      for (int a = 0; a < X; ++a) xt[a] = w.gxdt[(cb * RM + j) * X + a];
+      M::obs_hess_vec(traj + (size_t)(j + 1) * S * X, xt, hv);
+#pragma unroll
+      for (int a = 0; a < X; ++a) xb[a] = hv[a];
+    }
+  } else {
+    // x-bar arriving at this interval's end: the later intervals' hand-ons through their transition products
+    for (int m = bd.nobs - 1; m > j; --m) {
+      const double* gm = w.gbw + (cb * sy.NOBS + m) * NB;
+      const double* Pt = w.ivl + (cb * sy.NOBS + m) * NI + X * X + X * Z;
+      double nb[X];
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        double tt = gm[d];
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += xb[a] * Pt[a * X + d];
+        nb[d] = tt;
+      }
+#pragma unroll
+      for (int d = 0; d < X; ++d) xb[d] = nb[d];
+    }
+  }
+  const int ntile = (S + 63) >> 6;
+  for (int t = ntile - 1; t >= 0; --t) {
+    const int off = (t << 6) + (63 - lane);  // LATER steps in LOWER lanes
+    const bool valid = off < S;
+    const int s = j * S + off;
+    const size_t col = colb + (size_t)s * V;
+    double A[X * X], Bm[X * V], Zf[X * Z], x[X], vv[V], pb[X * V], qx[X * X];
+    if (valid) {
+#pragma unroll
+      for (int a = 0; a < X; ++a) x[a] = ld_stream(traj + (size_t)s * X + a);
+#pragma unroll
+      for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
+      if (PHASE == 0) {
+#pragma unroll
+        for (int k = 0; k < X * V; ++k) pb[k] = ld_stream(PBr + (size_t)s * (X * V) + k);
+#pragma unroll
+        for (int k = 0; k < X * X; ++k) qx[k] = ld_stream(Xq + (size_t)k * TS + s);
+      }
+      M::jac(cc.k, x, vv, A, Bm, Zf);
+    } else {
+#pragma unroll
+      for (int a = 0; a < X; ++a) x[a] = 0.0;
+#pragma unroll
+      for (int a = 0; a < V; ++a) vv[a] = 0.0;
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
+#pragma unroll
+      for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
+#pragma unroll
+      for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
+    }
+    if (PHASE != 0 || !valid) {
+#pragma unroll
+      for (int k = 0; k < X * V; ++k) pb[k] = 0.0;
+#pragma unroll
+      for (int k = 0; k < X * X; ++k) qx[k] = 0.0;
+    }
+    double Inc[X * X], E[X * X], PE[X * X];
+    dpp_prefix_products<X>(A, Inc, E);
+    matmul_xx<X>(Pf, E, PE);
+    double I0[X * X];
+#pragma unroll
+    for (int i = 0; i < X * X; ++i) I0[i] = bcast_lane63(Inc[i]);
+    if (PHASE == 0) {
+      double H[NXI];
+      {
+        double Q[X * NXI], Sm[X * NXI];
+#pragma unroll
+        for (int a1 = 0; a1 < X; ++a1) {
+#pragma unroll
+          for (int a2 = 0; a2 < X; ++a2) Q[a1 * NXI + a2] = qx[a1 * X + a2];
+#pragma unroll
+          for (int d = 0; d < V; ++d) {
+            double tt = 0.0;
+#pragma unroll
+            for (int a2 = 0; a2 < X; ++a2) tt += Cm[a1 * X + a2] * pb[a2 * V + d];
+            Q[a1 * NXI + X + d] = tt;
+          }
+#pragma unroll
+          for (int mz = 0; mz < Z; ++mz) Q[a1 * NXI + X + V + mz] = Qz[a1 * Z + mz];
+        }
+#pragma unroll
+        for (int a = 0; a < X; ++a)
+#pragma unroll
+          for (int m2 = 0; m2 < NXI; ++m2) {
+            double tt = 0.0;
+#pragma unroll
+            for (int a1 = 0; a1 < X; ++a1) tt += PE[a1 * X + a] * Q[a1 * NXI + m2];
+            Sm[a * NXI + m2] = tt;
+          }
+        M::hess(cc.k, x, vv, Sm, H);
+        if (!valid) {
+#pragma unroll
+          for (int i = 0; i < NXI; ++i) H[i] = 0.0;
+        }
+      }
+      double I2[X * X], gi[X];
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) I2[i] = A[i];
+#pragma unroll
+      for (int a = 0; a < X; ++a) gi[a] = H[a];
+      dpp_rowaffine_prefix<X>(I2, gi);
+      double xbs[X];
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        double tt = dpp_mov<0x138, 0xf, 0xf>(gi[d], 0.0);
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += xb[a] * E[a * X + d];
+        xbs[d] = tt;
+      }
+      if (valid) {
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          double tt = H[X + d];
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt += Bm[a * V + d] * xbs[a];
+          gv[col + d] = tt;
+        }
+      }
+#pragma unroll
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt = H[X + V + mz];
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += Zf[a * Z + mz] * xbs[a];
+        zbt[mz] += tt;
+      }
+      double g0[X], nb[X];
+#pragma unroll
+      for (int a = 0; a < X; ++a) g0[a] = bcast_lane63(gi[a]);
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        double tt = g0[d];
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += xb[a] * I0[a * X + d];
+        nb[d] = tt;
+      }
+#pragma unroll
+      for (int d = 0; d < X; ++d) xb[d] = nb[d];
+      double Pn[X * X];
+      matmul_xx<X>(Pf, I0, Pn);
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Pf[i] = Pn[i];
+    } else {
+      // the incoming x-bar at the state after this lane's step: xb (at the interval's end) through the later steps
+      double xc[X];
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        double tt = 0.0;
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += xb[a] * PE[a * X + d];
+        xc[d] = tt;
+      }
+      if (valid) {
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          double tt = 0.0;
+#pragma unroll
+          for (int a = 0; a < X; ++a) tt += Bm[a * V + d] * xc[a];
+          gv[col + d] += tt;
+        }
+      }
+#pragma unroll
+      for (int mz = 0; mz < Z; ++mz) {
+        double tt = 0.0;
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += Zf[a * Z + mz] * xc[a];
+        zbt[mz] += tt;
+      }
+      double Pn[X * X];
+      matmul_xx<X>(Pf, I0, Pn);
+#pragma unroll
+      for (int i = 0; i < X * X; ++i) Pf[i] = Pn[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < Z; ++i) {
+    double v = zbt[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    zbt[i] = v;
+  }
+  if (lane == 0) {
+    if (PHASE == 0) {
+#pragma unroll
+      for (int a = 0; a < X; ++a) gb[a] = xb[a];
+    }
+#pragma unroll
+    for (int i = 0; i < Z; ++i) gb[X + PHASE * Z + i] = zbt[i];
+  }
+}
+
+template <class M, int RM>
+__global__ void __launch_bounds__(64) k_gld_ivl_finish(Sys sy, Slots sl, Work w, int which) {
+  constexpr int X = M::X, Z = M::Z, U = M::U, V0 = M::V0;
+  constexpr int NI = CHMC_IVL_N(X, Z), NB = CHMC_GBW_N(X, Z);
+  const int tid = blockIdx.x * 64 + threadIdx.x;
+  if (tid >= sy.B * sy.K) return;
+  const int c = tid / sy.K, b = tid - c * sy.K;
+  if (!w.ok[c]) return;
+  const BlockDesc bd = sy.blk[b];
+  const int s_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
+  double* gv = pick(sl.grad, s_) + (size_t)c * sy.Q + sy.U;
+  double xb[X], zbt[Z];
+  for (int a = 0; a < X; ++a) xb[a] = 0.0;
+  for (int i = 0; i < Z; ++i) zbt[i] = 0.0;
+  for (int m = bd.nobs - 1; m >= 0; --m) {  // x-bar at the block's start; z-bar sums of both phases
+    const double* gm = w.gbw + (cb * sy.NOBS + m) * NB;
+    const double* Pt = w.ivl + (cb * sy.NOBS + m) * NI + X * X + X * Z;
+    double nb[X];
+    for (int d = 0; d < X; ++d) {
+      double tt = gm[d];
+      for (int a = 0; a < X; ++a) tt += xb[a] * Pt[a * X + d];
+      nb[d] = tt;
+    }
+    for (int d = 0; d < X; ++d) xb[d] = nb[d];
+    for (int i = 0; i < Z; ++i) zbt[i] += gm[X + i] + gm[X + Z + i];
+  }
+  if (bd.first) {
+    double dz[X * Z], dv0[X * V0];
+    M::gx0_jac(dz, dv0);
+    for (int d = 0; d < V0; ++d) {
+      double tt = 0.0;
+      for (int a = 0; a < X; ++a) tt += dv0[a * V0 + d] * xb[a];
+      gv[d] = tt;
+    }
+    for (int mz = 0; mz < Z; ++mz) {
+      double tt = 0.0;
+      for (int a = 0; a < X; ++a) tt += dz[a * Z + mz] * xb[a];
+      zbt[mz] += tt;
+    }
+  }
+  double Gz[Z * Z], gu[U];
+  M::gz_jac(q, Gz);
+  for (int d = 0; d < Z; ++d) {
+    double tt = 0.0;
+    for (int mz = 0; mz < Z; ++mz) tt += Gz[mz * Z + d] * zbt[mz];
+    gu[d] = tt;
+  }
+  for (int i = 0; i < RM; ++i) {
+    double o[Z], wu[U], zb[Z];
+    for (int d = 0; d < U; ++d) wu[d] = w.gWu[(cb * RM + i) * U + d];
+    for (int mz = 0; mz < Z; ++mz) zb[mz] = w.zbP[(cb * RM + i) * Z + mz];
+    M::gz_hess(q, wu, zb, o);
+    for (int d = 0; d < Z; ++d) gu[d] += o[d];
+  }
+  if constexpr (M::VS)  // variable observation noise: the sigma-dependent entries of J (see var_sigma_grad_terms)
+    gu[Z] = var_sigma_grad_terms<RM>(sy, bd, q, w.gWu + cb * RM * U, U, w.gMb + cb * RM * RM,
+                                     pick(sl.grad, s_) + (size_t)c * sy.Q);
+  for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
+}
+
 // The same backward sweep for 16-row blocks.  With 16 rows the row loops of k_gld_bwd_wave cannot be unrolled (register
 // file) and, rolled, they index per-lane arrays at run time, which puts those arrays into scratch memory (4.0 ms per
 // launch on the SIR single-block layout).  Here the row loop stays rolled but everything it indexes by the row lives in
@@ -3275,314 +3797,6 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave_ldsrows(Sys sy, Slots sl, 
     zbt[i] = v;
   }
   if (lane == 0) {
-    double Gz[Z * Z], gu[U];
-    M::gz_jac(q, Gz);
-    for (int d = 0; d < Z; ++d) {
-      double tt = 0.0;
-      for (int mz = 0; mz < Z; ++mz) tt += Gz[mz * Z + d] * zbt[mz];
-      gu[d] = tt;
-    }
-    for (int i = 0; i < RM; ++i) {
-      double o[Z], wu[U], zb[Z];
-      for (int d = 0; d < U; ++d) wu[d] = w.gWu[(cb * RM + i) * U + d];
-      for (int mz = 0; mz < Z; ++mz) zb[mz] = w.zbP[(cb * RM + i) * Z + mz];
-      M::gz_hess(q, wu, zb, o);
-      for (int d = 0; d < Z; ++d) gu[d] += o[d];
-    }
-    if constexpr (M::VS)  // variable observation noise: the sigma-dependent entries of J (see var_sigma_grad_terms)
-      gu[Z] = var_sigma_grad_terms<RM>(sy, bd, q, w.gWu + cb * RM * U, U, w.gMb + cb * RM * RM,
-                                       pick(sl.grad, s_) + (size_t)c * sy.Q);
-    for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
-  }
-}
-
-// The 16-row backward sweep with the rows of a block dealt out to the NSPLIT wavefronts of one workgroup (few long blocks:
-// the SIR single-block layout leaves three quarters of the SIMDs empty at one wavefront per block).  Everything the sweep
-// accumulates is LINEAR in the per-row terms -- the Hessian contraction source Sm, hence H, the second-order adjoint x-bar
-// with its carries, the gradient entries and z-bar -- so every wavefront runs the whole recursion for ITS rows (RH adjoint
-// rows in registers, fully unrolled: no run-time row index, no LDS row state) and the partial gradient entries of a tile are
-// summed through LDS in a fixed order (one workgroup barrier per tile, double-buffered).  The step's own derivatives
-// (jac, prefix products, Hessian contraction) are recomputed by every wavefront; the weights w_i come from the compact rows
-// (MLF[m] PB[s], as in the forward sweep) and only the wavefront's own tangents are read.
-template <class M, int RM, int NSPLIT>
-__global__ void __launch_bounds__(64 * NSPLIT) k_gld_bwd_wave_rowsplit(Sys sy, Slots sl, Work w, int which) {
-  constexpr int X = M::X, V = M::V, Z = M::Z, U = M::U, V0 = M::V0, NXI = M::NXI;
-  constexpr int RH = RM / NSPLIT;
-  static_assert(RM % NSPLIT == 0 && NSPLIT > 1, "equal shares of the rows");
-  __shared__ double sm[NSPLIT][RM * RM + RM * Z + RM * X];
-  __shared__ double sG[2][NSPLIT - 1][V][64];
-  __shared__ double sEnd[NSPLIT][X + Z];
-  const int lane = threadIdx.x & 63;
-  const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int r0 = h * RH;
-  const int wid = blockIdx.x;
-  if (wid >= sy.B * sy.K) return;
-  const int cbi = sy.order[wid];  // work order: longest blocks first
-  const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (!w.ok[c]) return;  // (the whole workgroup)
-  const BlockDesc bd = sy.blk[b];
-  const int s_ = sl.cur[c] ^ which;
-  const size_t cb = (size_t)c * sy.Kmax + b;
-  const int S = sy.S;
-  const size_t TS = (size_t)sy.T * S;
-  const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
-  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
-  const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
-  const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
-  const double* Xd = w.Xd + (size_t)c * RM * X * TS + bd.step0;
-  const double* PBr = pick(sl.PB, s_) + ((size_t)c * TS + bd.step0) * (X * V);
-  const double* LFr = pick(sl.LF, s_) + cb * sy.NOBS * RM * X;
-  double* gv = pick(sl.grad, s_) + (size_t)c * sy.Q + sy.U;
-  double* Mb = sm[h];
-  double* zd = sm[h] + RM * RM;
-  double* MLFs = sm[h] + RM * RM + RM * Z;
-  auto lds_sync = [&]() {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-  };
-  for (int i = lane; i < RM * RM; i += 64) Mb[i] = w.gMb[cb * RM * RM + i];
-  for (int i = lane; i < RM * Z; i += 64) zd[i] = w.gzd[cb * RM * Z + i];
-  lds_sync();
-  ChainConsts<M> cc;
-  cc.init(q, sy.dl);
-  double Lam[RH * X], zdr[RH * Z], mlf[RH * X];  // this wavefront's adjoint rows (wave-uniform), z-tangents, weights' frames
-#pragma unroll
-  for (int i = 0; i < RH * X; ++i) Lam[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < RH * Z; ++i) zdr[i] = zd[r0 * Z + i];
-  double xb[X], zbt[Z];
-#pragma unroll
-  for (int i = 0; i < X; ++i) xb[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < Z; ++i) zbt[i] = 0.0;
-  const int ntile = (S + 63) >> 6;
-  int buf = 0;
-  for (int j = bd.nobs - 1; j >= 0; --j) {
-    if (j < bd.ny && j >= r0 && j < r0 + RH) {  // the observation row of this interval's end belongs to this wavefront
-      double g[X], hv[X], xt[X];
-      for (int a = 0; a < X; ++a) xt[a] = w.gxdt[(cb * RM + j) * X + a];
-      M::obs_grad(traj + (size_t)(j + 1) * S * X, g);
-      M::obs_hess_vec(traj + (size_t)(j + 1) * S * X, xt, hv);
-#pragma unroll
-      for (int i = 0; i < RH; ++i)
-        if (r0 + i == j) {
-#pragma unroll
-          for (int a = 0; a < X; ++a) Lam[i * X + a] = g[a];
-        }
-#pragma unroll
-      for (int a = 0; a < X; ++a) xb[a] += hv[a];
-    }
-    if (j == bd.nobs - 1 && !bd.last) {  // state rows ny .. ny + X of a block that ends inside the sequence
-#pragma unroll
-      for (int i = 0; i < RH; ++i)
-#pragma unroll
-        for (int a = 0; a < X; ++a)
-          if (r0 + i == bd.ny + a) Lam[i * X + a] = 1.0;
-    }
-    {  // MLF[j] = (G^-1)_bb LF[j], one entry per lane, then this wavefront's rows to registers
-      lds_sync();
-      if (lane < RM * X) {
-        const int i = lane / X, a = lane - i * X;
-        double t = 0.0;
-        for (int jj = 0; jj < RM; ++jj) t += Mb[i * RM + jj] * LFr[((size_t)j * RM + jj) * X + a];
-        MLFs[lane] = t;
-      }
-      lds_sync();
-#pragma unroll
-      for (int e2 = 0; e2 < RH * X; ++e2) mlf[e2] = MLFs[r0 * X + e2];
-    }
-    for (int t = ntile - 1; t >= 0; --t) {
-      const int off = (t << 6) + (63 - lane);  // LATER steps in LOWER lanes: the suffix scans become DPP prefix scans
-      const bool valid = off < S;
-      const int s = j * S + off;
-      const size_t col = colb + (size_t)s * V;
-      double A[X * X], Bm[X * V], Zf[X * Z], x[X], vv[V], pb[X * V];
-      if (valid) {
-#pragma unroll
-        for (int a = 0; a < X; ++a) x[a] = ld_stream(traj + (size_t)s * X + a);
-#pragma unroll
-        for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
-#pragma unroll
-        for (int k = 0; k < X * V; ++k) pb[k] = ld_stream(PBr + (size_t)s * (X * V) + k);
-        M::jac(cc.k, x, vv, A, Bm, Zf);
-      } else {
-#pragma unroll
-        for (int a = 0; a < X; ++a) x[a] = 0.0;
-#pragma unroll
-        for (int a = 0; a < V; ++a) vv[a] = 0.0;
-#pragma unroll
-        for (int k = 0; k < X * V; ++k) pb[k] = 0.0;
-#pragma unroll
-        for (int i = 0; i < X * X; ++i) A[i] = (i / X == i % X) ? 1.0 : 0.0;
-#pragma unroll
-        for (int i = 0; i < X * V; ++i) Bm[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < X * Z; ++i) Zf[i] = 0.0;
-      }
-      // products of the transition matrices of the later steps (adjoint rows): exclusive prefix products over the lanes
-      double Inc[X * X], E[X * X];
-      dpp_prefix_products<X>(A, Inc, E);
-      // Hessian contraction source of this step, this wavefront's rows
-      double H[NXI];
-      {
-        double Sm[X * NXI];
-#pragma unroll
-        for (int i = 0; i < X * NXI; ++i) Sm[i] = 0.0;
-#pragma unroll
-        for (int i = 0; i < RH; ++i) {
-          const bool act = valid && r0 + i >= j && r0 + i < bd.nrows;
-          double Ls[X], dir[NXI];
-#pragma unroll
-          for (int d = 0; d < X; ++d) {
-            double tt = 0.0;
-#pragma unroll
-            for (int a = 0; a < X; ++a) tt += Lam[i * X + a] * E[a * X + d];
-            Ls[d] = tt;
-          }
-#pragma unroll
-          for (int a = 0; a < X; ++a) dir[a] = act ? Xd[(size_t)((r0 + i) * X + a) * TS + s] : 0.0;
-#pragma unroll
-          for (int d = 0; d < V; ++d) {
-            double tt = 0.0;
-#pragma unroll
-            for (int a = 0; a < X; ++a) tt += mlf[i * X + a] * pb[a * V + d];
-            dir[X + d] = tt;
-          }
-#pragma unroll
-          for (int mz = 0; mz < Z; ++mz) dir[X + V + mz] = zdr[i * Z + mz];
-#pragma unroll
-          for (int a = 0; a < X; ++a)
-#pragma unroll
-            for (int m2 = 0; m2 < NXI; ++m2) Sm[a * NXI + m2] += Ls[a] * dir[m2];
-        }
-        M::hess(cc.k, x, vv, Sm, H);
-        if (!valid) {
-#pragma unroll
-          for (int i = 0; i < NXI; ++i) H[i] = 0.0;
-        }
-      }
-      // joint suffix scan for x-bar: x-bar^(l) = x-bar^(l+1) A_l + Hx_l
-      double I2[X * X], gi[X];
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) I2[i] = A[i];
-#pragma unroll
-      for (int a = 0; a < X; ++a) gi[a] = H[a];
-      dpp_rowaffine_prefix<X>(I2, gi);
-      double xbs[X];  // x-bar at the state after this lane's step
-#pragma unroll
-      for (int d = 0; d < X; ++d) {
-        double tt = dpp_mov<0x138, 0xf, 0xf>(gi[d], 0.0);  // wave_shr:1: the sources of the later steps
-#pragma unroll
-        for (int a = 0; a < X; ++a) tt += xb[a] * E[a * X + d];
-        xbs[d] = tt;
-      }
-      // this wavefront's share of the gradient entries of the tile, summed over the wavefronts in a fixed order
-      double pv[V];
-#pragma unroll
-      for (int d = 0; d < V; ++d) {
-        double tt = H[X + d];
-#pragma unroll
-        for (int a = 0; a < X; ++a) tt += Bm[a * V + d] * xbs[a];
-        pv[d] = tt;
-      }
-      if (h > 0) {
-#pragma unroll
-        for (int d = 0; d < V; ++d) sG[buf][h - 1][d][lane] = pv[d];
-      }
-      __syncthreads();
-      if (h == 0 && valid) {
-#pragma unroll
-        for (int d = 0; d < V; ++d) {
-          double tt = pv[d];
-#pragma unroll
-          for (int k = 0; k < NSPLIT - 1; ++k) tt += sG[buf][k][d][lane];
-          gv[col + d] = tt;
-        }
-      }
-      buf ^= 1;
-#pragma unroll
-      for (int mz = 0; mz < Z; ++mz) {
-        double tt = H[X + V + mz];
-#pragma unroll
-        for (int a = 0; a < X; ++a) tt += Zf[a * Z + mz] * xbs[a];
-        zbt[mz] += tt;
-      }
-      // carries
-      double I0[X * X], g0[X];
-#pragma unroll
-      for (int i = 0; i < X * X; ++i) I0[i] = bcast_lane63(I2[i]);
-#pragma unroll
-      for (int a = 0; a < X; ++a) g0[a] = bcast_lane63(gi[a]);
-      {
-        double nb[X];
-#pragma unroll
-        for (int d = 0; d < X; ++d) {
-          double tt = g0[d];
-#pragma unroll
-          for (int a = 0; a < X; ++a) tt += xb[a] * I0[a * X + d];
-          nb[d] = tt;
-        }
-#pragma unroll
-        for (int d = 0; d < X; ++d) xb[d] = nb[d];
-      }
-#pragma unroll
-      for (int i = 0; i < RH; ++i) {  // Lam <- Lam I0
-        double nl[X];
-#pragma unroll
-        for (int d = 0; d < X; ++d) {
-          double tt = 0.0;
-#pragma unroll
-          for (int a = 0; a < X; ++a) tt += Lam[i * X + a] * I0[a * X + d];
-          nl[d] = tt;
-        }
-#pragma unroll
-        for (int d = 0; d < X; ++d) Lam[i * X + d] = nl[d];
-      }
-    }
-  }
-  // the wavefronts' x-bar at the block start and their z-bar sums, added up by wavefront 0
-#pragma unroll
-  for (int i = 0; i < Z; ++i) {
-    double v = zbt[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    zbt[i] = v;
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int a = 0; a < X; ++a) sEnd[h][a] = xb[a];
-#pragma unroll
-    for (int i = 0; i < Z; ++i) sEnd[h][X + i] = zbt[i];
-  }
-  __syncthreads();
-  if (h != 0 || lane != 0) return;
-#pragma unroll
-  for (int a = 0; a < X; ++a) {
-    double tt = sEnd[0][a];
-    for (int k = 1; k < NSPLIT; ++k) tt += sEnd[k][a];
-    xb[a] = tt;
-  }
-#pragma unroll
-  for (int i = 0; i < Z; ++i) {
-    double tt = sEnd[0][X + i];
-    for (int k = 1; k < NSPLIT; ++k) tt += sEnd[k][X + i];
-    zbt[i] = tt;
-  }
-  if (bd.first) {
-    double dz[X * Z], dv0[X * V0];
-    M::gx0_jac(dz, dv0);
-    for (int d = 0; d < V0; ++d) {
-      double tt = 0.0;
-      for (int a = 0; a < X; ++a) tt += dv0[a * V0 + d] * xb[a];
-      gv[d] = tt;
-    }
-    for (int mz = 0; mz < Z; ++mz) {
-      double tt = 0.0;
-      for (int a = 0; a < X; ++a) tt += dz[a * Z + mz] * xb[a];
-      zbt[mz] += tt;
-    }
-  }
-  {
     double Gz[Z * Z], gu[U];
     M::gz_jac(q, Gz);
     for (int d = 0; d < Z; ++d) {

@@ -903,15 +903,17 @@ def test_time_parallel_scan_absorbed_and_nan_trajectories(monkeypatch):
     assert np.isfinite(xs).sum() >= B // 4
 
 
-@pytest.mark.parametrize("split", ["1", "2", "4"])
+@pytest.mark.parametrize("split", ["1", "4"])
 @pytest.mark.parametrize("T,S,R,B", [(14, 200, 14, 3), (26, 24, 13, 5), (16, 72, 16, 2)])
 def test_sixteen_row_blocks_row_split_settings(monkeypatch, split, T, S, R, B):
-    """16-row blocks (SIR): the state evaluation with the rows of a block dealt out to 1, 2 or 4 wavefronts
-    (CHMC_ROW_SPLIT; 1 = the stored-rows sweep k_rev_wave_ldsrows + k_gram_rows + k_gld_bwd_wave_ldsrows that large batches
-    keep, 2 / 4 = the interval-parallel sweep on the compact rows + k_gld_bwd_wave_rowsplit) against the C oracle: every
-    per-operator entry point (chol_gram_blocks :794-810, grad_log_det_sqrt_gram :1143-1146, jacob_constr_blocks :704-763
-    -- the rows are rebuilt from the compact form on demand) and two leapfrog steps; single-block layout at full size,
-    two blocks per chain (13 observation rows + 3 state rows, then 13 rows) and a full 16-row block."""
+    """16-row blocks (SIR): the two state evaluations (CHMC_ROW_SPLIT=1: the stored-rows sweeps k_rev_wave_ldsrows +
+    k_gram_rows + k_gld_fwd_wave + k_gld_bwd_wave_ldsrows that large batches keep; otherwise, the default for up to 1 024
+    blocks: the interval-parallel sweep on the compact rows k_newton_ivl / k_newton_comb<STATE> and the row-free grad-log-det
+    sweeps with every observation interval on its own wavefront, k_gld_ivl_prologue / k_gld_fwd_ivl / k_gld_bwd_ivl<0, 1> /
+    k_gld_ivl_finish) against the C oracle: every per-operator entry point (chol_gram_blocks :794-810,
+    grad_log_det_sqrt_gram :1143-1146, jacob_constr_blocks :704-763 -- the rows are rebuilt from the compact form on demand)
+    and two leapfrog steps; single-block layout at full size, two blocks per chain (13 observation rows + 3 state rows, then
+    13 rows) and a full 16-row block."""
     monkeypatch.setenv("CHMC_ROW_SPLIT", split)
     case = make_case("sir", T, S, R, True, B=B, seed=23 + T, obs_interval=0.25)
     ctx = make_ctx(case)
