@@ -129,7 +129,7 @@ def check_kernel(name, body):
 
 
 NO_SPILL = ("k_newton_leanINS_8FhnModelELi7ELb0", "k_rev_waveINS_8FhnModelELi7E", "k_gld_fwd_waveINS_8FhnModelELi7E",
-            "k_gld_bwd_waveINS_8FhnModelELi7E")  # the hot instantiations of the headline configuration
+            "k_gld_bwd_waveINS_8FhnModelELi7E", "k_gld_fwd_qxINS_8FhnModelELi7E")  # the hot instantiations of the headline configuration
 
 
 def audit_stores(name, body):
