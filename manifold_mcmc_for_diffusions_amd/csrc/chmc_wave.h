@@ -2067,14 +2067,12 @@ __global__ void __launch_bounds__(256) k_jw_pb(Sys sy, Slots sl, Work w, int whi
 template <class M, int RM, bool PBJ = false, bool QX = false>
 __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, int which) {
   constexpr int X = M::X, V = M::V, Z = M::Z, V0 = M::V0;
-  constexpr int RH = RM, NSPLIT = 1;  // (a row split over NSPLIT wavefronts was built and superseded by k_gld_fwd_ivl: DESIGN.md)
   constexpr int URM = 64;  // (the forward sweep is correct fully unrolled at 16 rows as well; the backward sweep is not, see there)
   __shared__ double sm[4][RM * RM + RM * Z + (PBJ ? RM * X : 0)];
   const int lane = threadIdx.x & 63;
   const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wid0 = blockIdx.x * (blockDim.x >> 6) + wv_;
-  if (wid0 >= sy.B * sy.K * NSPLIT) return;
-  const int wid = wid0 / NSPLIT, r0 = (wid0 - wid * NSPLIT) * RH;  // rows r0 .. r0 + RH of the block
+  const int wid = blockIdx.x * (blockDim.x >> 6) + wv_;
+  if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];  // work order: longest blocks first
   const int c = cbi / sy.K, b = cbi - c * sy.K;
   if (!w.ok[c]) return;
@@ -2100,22 +2098,22 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   ChainConsts<M> cc;
   cc.init(q, sy.dl);
-  double mlf[PBJ ? RH * X : 1], lf[QX ? RM * X : 1];
-  double xdc[RH * X];  // tangents at the start of the current tile (wave-uniform)
+  double mlf[PBJ ? RM * X : 1], lf[QX ? RM * X : 1];
+  double xdc[RM * X];  // tangents at the start of the current tile (wave-uniform)
 #pragma unroll URM
-  for (int i = 0; i < RH * X; ++i) xdc[i] = 0.0;
+  for (int i = 0; i < RM * X; ++i) xdc[i] = 0.0;
   if (bd.first) {
     double dz[X * Z], dv0[X * V0];
     M::gx0_jac(dz, dv0);
 #pragma unroll URM
-    for (int i = 0; i < RH; ++i)
+    for (int i = 0; i < RM; ++i)
 #pragma unroll
       for (int a = 0; a < X; ++a) {
         double t = 0.0;
-        for (int mz = 0; mz < Z; ++mz) t += dz[a * Z + mz] * zd[(r0 + i) * Z + mz];
+        for (int mz = 0; mz < Z; ++mz) t += dz[a * Z + mz] * zd[i * Z + mz];
         for (int d = 0; d < V0; ++d) {
           double wv = 0.0;
-          for (int jj = 0; jj < RM; ++jj) wv += Mb[(r0 + i) * RM + jj] * Jv[(size_t)jj * NV + d];
+          for (int jj = 0; jj < RM; ++jj) wv += Mb[i * RM + jj] * Jv[(size_t)jj * NV + d];
           t += dv0[a * V0 + d] * wv;
         }
         xdc[i * X + a] = t;
@@ -2135,7 +2133,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int e2 = 0; e2 < RH * X; ++e2) mlf[e2] = MLFs[r0 * X + e2];
+      for (int e2 = 0; e2 < RM * X; ++e2) mlf[e2] = MLFs[e2];
       if constexpr (QX) {
 #pragma unroll
         for (int e2 = 0; e2 < RM * X; ++e2) lf[e2] = LFr[(size_t)j * RM * X + e2];
@@ -2145,7 +2143,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
       const int off = (t << 6) + lane;
       const bool valid = off < S;
       const int s = j * S + off;
-      double P[X * X], e[RH * X];
+      double P[X * X], e[RM * X];
       {
         double A[X * X], Bm[X * V], Zf[X * Z], jp[PBJ ? X * V : RM * V];
         if (valid) {
@@ -2180,7 +2178,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
 #pragma unroll
         for (int i = 0; i < X * X; ++i) P[i] = A[i];
 #pragma unroll URM
-        for (int i = 0; i < RH; ++i) {
+        for (int i = 0; i < RM; ++i) {
           double wv[V];
 #pragma unroll
           for (int d = 0; d < V; ++d) {
@@ -2190,7 +2188,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
               for (int a = 0; a < X; ++a) tt += mlf[i * X + a] * jp[a * V + d];
             } else {
 #pragma unroll URM
-              for (int jj = 0; jj < RM; ++jj) tt += Mb[(r0 + i) * RM + jj] * jp[jj * V + d];
+              for (int jj = 0; jj < RM; ++jj) tt += Mb[i * RM + jj] * jp[jj * V + d];
             }
             wv[d] = tt;
           }
@@ -2200,25 +2198,25 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
 #pragma unroll
             for (int d = 0; d < V; ++d) tt += Bm[a * V + d] * wv[d];
 #pragma unroll
-            for (int mz = 0; mz < Z; ++mz) tt += Zf[a * Z + mz] * zd[(r0 + i) * Z + mz];
+            for (int mz = 0; mz < Z; ++mz) tt += Zf[a * Z + mz] * zd[i * Z + mz];
             e[i * X + a] = tt;
           }
         }
       }
       // inclusive affine prefix scan: (P, e)_l maps the tangents at the tile start to those after step l
-      if constexpr (RH <= CHMC_GLD_FWD_DPP_MAXROWS) {
-        dpp_affine_prefix<X, RH>(P, e);  // DPP path of the vector ALU (the shuffle version below waits on the LDS crossbar)
+      if constexpr (RM <= CHMC_GLD_FWD_DPP_MAXROWS) {
+        dpp_affine_prefix<X, RM>(P, e);  // DPP path of the vector ALU (the shuffle version below waits on the LDS crossbar)
       } else {
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-          double Pp[X * X], ep[RH * X], Pn[X * X];
+          double Pp[X * X], ep[RM * X], Pn[X * X];
 #pragma unroll
           for (int i = 0; i < X * X; ++i) Pp[i] = __shfl_up(P[i], o, 64);
 #pragma unroll URM
-          for (int i = 0; i < RH * X; ++i) ep[i] = __shfl_up(e[i], o, 64);
+          for (int i = 0; i < RM * X; ++i) ep[i] = __shfl_up(e[i], o, 64);
           if (lane >= o) {
 #pragma unroll URM
-            for (int i = 0; i < RH; ++i)
+            for (int i = 0; i < RM; ++i)
 #pragma unroll
               for (int a = 0; a < X; ++a) {
                 double tt = e[i * X + a];
@@ -2234,16 +2232,16 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
       }
       // exclusive values: tangents AT this lane's step
       {
-        double xs[RH * X];
+        double xs[RM * X];
 #pragma unroll URM
-        for (int i = 0; i < RH; ++i)
+        for (int i = 0; i < RM; ++i)
 #pragma unroll
           for (int a = 0; a < X; ++a) xs[i * X + a] = dpp_mov<0x138, 0xf, 0xf>(e[i * X + a], 0.0);  // wave_shr:1
         double Pex[X * X];
 #pragma unroll
         for (int i = 0; i < X * X; ++i) Pex[i] = dpp_mov<0x138, 0xf, 0xf>(P[i], (i / X == i % X) ? 1.0 : 0.0);
 #pragma unroll URM
-        for (int i = 0; i < RH; ++i)
+        for (int i = 0; i < RM; ++i)
 #pragma unroll
           for (int a = 0; a < X; ++a) {
             double tt = xs[i * X + a];
@@ -2266,20 +2264,20 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
         } else
         if (valid) {  // the tangent of row i is only needed up to that row's own observation time
 #pragma unroll URM
-          for (int i = 0; i < RH; ++i)
-            if (r0 + i >= j && r0 + i < bd.nrows) {
+          for (int i = 0; i < RM; ++i)
+            if (i >= j && i < bd.nrows) {
 #pragma unroll
-              for (int a = 0; a < X; ++a) st_async(Xd + (size_t)((r0 + i) * X + a) * TS + s, xs[i * X + a]);
+              for (int a = 0; a < X; ++a) st_async(Xd + (size_t)(i * X + a) * TS + s, xs[i * X + a]);
             }
         }
       }
       // carry to the next tile: apply lane 63's inclusive map
       {
-        double P6[X * X], nx[RH * X];
+        double P6[X * X], nx[RM * X];
 #pragma unroll
         for (int i = 0; i < X * X; ++i) P6[i] = bcast_lane63(P[i]);
 #pragma unroll URM
-        for (int i = 0; i < RH; ++i)
+        for (int i = 0; i < RM; ++i)
 #pragma unroll
           for (int a = 0; a < X; ++a) {
             double tt = bcast_lane63(e[i * X + a]);
@@ -2288,14 +2286,14 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
             nx[i * X + a] = tt;
           }
 #pragma unroll URM
-        for (int i = 0; i < RH * X; ++i) xdc[i] = nx[i];
+        for (int i = 0; i < RM * X; ++i) xdc[i] = nx[i];
       }
     }
     // tangent of observation row j at its terminal time (j + 1) S
     if (j < bd.ny && lane == 0) {
 #pragma unroll URM
-      for (int i = 0; i < RH; ++i)
-        if (r0 + i == j)
+      for (int i = 0; i < RM; ++i)
+        if (i == j)
 #pragma unroll
           for (int a = 0; a < X; ++a) w.gxdt[(cb * RM + j) * X + a] = xdc[i * X + a];
     }
