@@ -289,3 +289,35 @@ def test_variable_observation_noise_block_metric(emu_lib, model, T, S, R):
     ctx = make_ctx(case)
     check_block_metric_against_oracle(ctx, case, True, np.array([0.05, -0.05, 0.08, 0.02]))
     ctx.close()
+
+
+def test_adam_update_entry_point(emu_lib):
+    """chmc_adam_update_device (the Adam step of a device-resident iteration of
+    find_initial_state_by_gradient_descent_noisy_system, sde/mici_extensions.py:1679-1801) on the host emulation, where
+    "device" buffers are host arrays: equal to NumPy, a non-finite gradient entry counts as zero in the moments and a
+    zero learning rate keeps a chain's parameters.  (The objective half, chmc_adam_objective_device, runs wave kernels: GPU
+    test in test_hip_surface.py.)"""
+    from manifold_mcmc_for_diffusions_amd.context import ChmcContext
+    counts = np.array([3.0, 8.0, 28.0, 75.0, 221.0])
+    B, T, S = 5, len(counts), 6
+    ctx = ChmcContext("sir", 1.0, S, T, counts, sigma=1.0, num_chains=B)
+    n = ctx.Q - T
+    rng = np.random.default_rng(8)
+    u_v = np.ascontiguousarray(0.4 * rng.standard_normal((B, n)))
+    g = rng.standard_normal((B, n))
+    g[1, 3] = np.nan
+    m0, v0 = rng.standard_normal((B, n)), rng.random((B, n))
+    m, v, u = m0.copy(), v0.copy(), u_v.copy()
+    tt = np.array([1.0, 2.0, 5.0, 9.0, 30.0])
+    lr = np.array([0.1, 0.1, 0.0, 0.1, 0.1]) / (1 - 0.9 ** tt)
+    coef = np.stack([1.0 / (1 - 0.999 ** tt), lr], 1)
+    ctx.adam_update_device(u.ctypes.data, m.ctypes.data, v.ctypes.data, g.ctypes.data, coef, 0.9, 0.999, 1e-8)
+    g0 = np.where(np.isfinite(g), g, 0.0)
+    m1, v1 = 0.9 * m0 + (1 - 0.9) * g0, 0.999 * v0 + (1 - 0.999) * g0 ** 2
+    np.testing.assert_allclose(m, m1, rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(v, v1, rtol=1e-13, atol=1e-15)
+    np.testing.assert_allclose(u, u_v - lr[:, None] * m1 / (np.sqrt(v1 * coef[:, :1]) + 1e-8), rtol=1e-13, atol=1e-15)
+    assert np.array_equal(u[2], u_v[2])
+    with pytest.raises(RuntimeError):
+        ctx.adam_objective_device(u.ctypes.data, g.ctypes.data)   # wave kernels only: reported, not emulated
+    ctx.close()
