@@ -4702,10 +4702,10 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
 // junction whose predecessor did not move gets EXACTLY F_l(U_l), so after j sweeps the first j segments are bitwise the
 // sequential recursion and the method terminates with the sequential result after at most 64 sweeps whatever the guess;
 // (iii) the trajectory entries are stored by the segment recursions themselves.  Sweeps repeat until no junction moved
-// by more than 1e-13 (relative).  Segments started from a useless guess may overflow; that is harmless (the exact prefix
+// by more than CHMC_PAR_JTOL = 3e-13 (relative).  Segments started from a useless guess may overflow; that is harmless (the exact prefix
 // reaches them), and where the true recursion itself overflows the NaNs are the result.  A block that is still not
 // settled after MAXS sweeps is integrated sequentially by lane 0 (counted in work.nfallback).  Because the sweeps stop
-// at 1e-13 relative -- not at bitwise-still junctions -- the result equals the sequential recursion to about 1e-13, NOT bit
+// at 3e-13 relative -- not at bitwise-still junctions -- the result equals the sequential recursion to about 1e-12, NOT bit
 // for bit; whether this kernel or the sequential scan runs depends on the batch (chmc_create: chains x blocks <= 1024), so
 // a chain's bits depend on the scan its shard selects (CHMC_PAR_SCAN fixes the choice; tests compare the two scans).
 // gsel: guess trajectory: 1 = the destination buffer itself (previous iterate), 2 = the state's trajectory (slot cur),
@@ -4730,6 +4730,15 @@ __global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, in
   // 22.7 k against 26.3 k steps/s.
   // (With several blocks per chain the chain's mask would be shared by wavefronts that settle and wavefronts that do not:
   // those layouts keep 12 sweeps and the sequential recursion inside the launch, as outside a loop.)
+// Junction tolerance (relative to max(|x|, 1)): a junction has settled when its new start state moved by no more than this.
+// Measured on boarding-school SIR, 256 chains, against the sequential scan over 12 288 chain-steps (tools/par_scan_compare.py,
+// step sizes 0.25 and 0.4): 1e-13: 47.2 k steps/s, statuses equal, 6 iteration counts differ, positions to 2.3e-13;
+// 3e-13: 49.5 k, statuses equal, 8 counts, 8.4e-13;  1e-12: 54.5 k, statuses equal, 76 counts, 3.0e-12 (the launches of a round
+// wait for their slowest chain, and the last sweeps of the slow ones only chase rounding);  1e-11: the retractions stop
+// converging (a constraint value is then uncertain by more than the constraint tolerance).
+#ifndef CHMC_PAR_JTOL
+#define CHMC_PAR_JTOL 3e-13
+#endif
 #ifndef CHMC_PAR_MAXS_ROUND
 #define CHMC_PAR_MAXS_ROUND 12  // measured at 256 boarding-school SIR chains: 4: 22.5 k, 6: 25.0 k, 8: 25.9 k, 10: 26.1 k, 12: 26.3 k, 16: 25.7 k steps/s
 #endif
@@ -4953,7 +4962,7 @@ __global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, in
         for (int a = 0; a < X; ++a) {
           const double nu = Un[a], old = Unext[a];
           const bool same = nu == old || (nu != nu && old != old);
-          const bool close = fabs(nu - old) <= 1e-13 * (fabs(nu) > 1.0 ? fabs(nu) : 1.0);
+          const bool close = fabs(nu - old) <= CHMC_PAR_JTOL * (fabs(nu) > 1.0 ? fabs(nu) : 1.0);
           u |= !(same || close);
         }
       }

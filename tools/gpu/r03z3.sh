@@ -21,10 +21,17 @@ PY
 find $O -name "*.csv" -size +4M -delete
 cp $O/traffic.json $R/profiles/traffic.json
 python bench.py > $O/bench_fhn_noisy_with_traffic.json 2> $O/bench.err || tail -5 $O/bench.err
-python bench.py --config sir --no-cpu-baseline > $O/bench_sir.json 2> $O/bench_sir.err
+python bench.py --config sir > $O/bench_sir.json 2> $O/bench_sir.err
+python bench.py --config sir --chains-per-gpu 1024 --no-cpu-baseline > $O/bench_sir_1024.json 2> $O/bench_sir_1024.err
+python bench.py --engine async --config sir --no-cpu-baseline > $O/bench_sir_engine_async.json 2> $O/bench_sir_async.err
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_sir -- python3 $R/bench.py --no-cpu-baseline --config sir > $O/prof_stats_sir.log 2>&1; cd $R
+cp $(find $O/prof_stats_sir -name "*kernel_stats.csv") $O/kernel_stats_sir.csv
+find $O/prof_stats_sir -name "*.csv" -size +4M -delete
+python examples/sir_boarding_school_chmc.py 256 300 100 16 > $O/example_sir_boarding_school_256.log 2>&1; tail -2 $O/example_sir_boarding_school_256.log
+python tools/adam_timing.py 1024 > $O/adam_init_1024.log 2>&1; tail -1 $O/adam_init_1024.log; python tools/adam_timing.py 256 > $O/adam_init_256.log 2>&1; tail -1 $O/adam_init_256.log
 python - <<'PY'
 import json
-for f in ('bench_fhn_noisy_with_traffic', 'bench_sir'):
+for f in ('bench_fhn_noisy_with_traffic', 'bench_sir', 'bench_sir_1024', 'bench_sir_engine_async'):
     d = json.loads(open(f'gpurun_out/r03z3/{f}.json').read().strip().splitlines()[-1]); r = d['roofline']
     print(f, round(d['value']), round(d['ms_per_step'], 3), r['bound'], round(r['frac'], 3), 'traffic', r.get('traffic'), 'whole', d['config'].get('whole_step_hbm_frac'))
 PY
