@@ -1058,6 +1058,152 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
   }
 }
 
+// The body of k_newton_factor_wave for the block (c, b) on the 16 lanes r = lane & 15 of a 16-lane group (act: this group has a
+// block and its chain is in the loop); Dsrc / Jusrc: the block's Gram matrix and dc/du rows of the iterate (global memory, or
+// the LDS copies of k_newton_comb<.., FACTOR>, which runs this right behind its combine step: one launch of a Newton round
+// less for one 16-row block per chain).
+template <class M, int RM, bool FUSE>
+__device__ __forceinline__ void newton_factor16(const Sys& sy, const Slots& sl, const Work& w, int prev, int qsel, int c, int b,
+                                                bool act, const double* Dsrc, const double* Jusrc) {
+  static_assert(RM == 16, "rows over 16 lanes");
+  constexpr int U = M::U, NC = RM + 1 + U;  // augmented row: D row | c | dc/du row
+  const int lane = threadIdx.x & 63, r = lane & 15;
+  const int sp = sl.cur[c] ^ prev;
+  const size_t cb = (size_t)c * sy.Kmax + b;
+  double a[NC];
+#pragma unroll
+  for (int k = 0; k < RM; ++k) a[k] = act ? Dsrc[r * RM + k] : (k == r ? 1.0 : 0.0);
+  a[RM] = act ? w.cpad[cb * RM + r] : 0.0;
+  const double c0 = a[RM];  // the constraint value of this row (|c|_inf of the iterate, FUSE)
+#pragma unroll
+  for (int d = 0; d < U; ++d) a[RM + 1 + d] = act ? Jusrc[r * U + d] : 0.0;
+#pragma unroll
+  for (int j = 0; j < RM; ++j) {
+    // pivot: largest |a_ij| over the rows i >= j, the first one on ties
+    double best = r >= j ? fabs(a[j]) : -1.0;
+    int bi = r;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(best, o, 16);
+      const int oi = __shfl_xor(bi, o, 16);
+      if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
+    }
+    const int p = bi;  // (uniform over the 16 lanes of the block)
+    const int partner = r == j ? p : (r == p ? j : r);
+    double pr[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+      a[k] = __shfl(a[k], partner, 16);  // exchange rows j and p
+      pr[k] = __shfl(a[k], j, 16);       // the pivot row
+    }
+    const double inv = 1.0 / pr[j];
+    if (r > j) {
+      const double l = a[j] * inv;
+      a[j] = l;
+#pragma unroll
+      for (int k = j + 1; k < NC; ++k) a[k] -= l * pr[k];
+    }
+  }
+  // back substitution of the 1 + U right-hand sides, column by column
+#pragma unroll
+  for (int k = RM - 1; k >= 0; --k) {
+    const double ukk = __shfl(a[k], k, 16);
+#pragma unroll
+    for (int d = 0; d < 1 + U; ++d) {
+      const double xk = __shfl(a[RM + d], k, 16) / ukk;
+      if (r == k) a[RM + d] = xk;
+      if (r < k) a[RM + d] -= a[k] * xk;
+    }
+  }
+  if (act) {
+    w.tpad[cb * RM + r] = a[RM];
+#pragma unroll
+    for (int d = 0; d < U; ++d) w.Ew[cb * RM * U + r * U + d] = a[RM + 1 + d];
+  }
+  // C_b = Ju_prev^T E, s_b = Ju_prev^T t: sums over the 16 rows
+  double jur[U];
+#pragma unroll
+  for (int d = 0; d < U; ++d) jur[d] = act ? pick(sl.JuP, sp)[cb * RM * U + r * U + d] : 0.0;
+  double sacc[U], Cm[U * U];
+#pragma unroll
+  for (int aa = 0; aa < U; ++aa) {
+    double v = jur[aa] * a[RM];
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    if (!FUSE && act && r == 0) w.sb[cb * U + aa] = v;
+    sacc[aa] = v;
+#pragma unroll
+    for (int d = 0; d < U; ++d) {
+      double t = jur[aa] * a[RM + 1 + d];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 16);
+      if (!FUSE && act && r == 0) w.Cb[(cb * U + aa) * U + d] = t;
+      Cm[aa * U + d] = t;
+    }
+  }
+  if constexpr (FUSE) {
+    // (every lane of the block holds s = s_b and C_b: the core system C = M_0 + C_b, y = C^-1 s, redundantly per lane)
+    constexpr int X = M::X;
+    __shared__ double lamS[4][RM];
+#pragma unroll
+    for (int i = 0; i < U * U; ++i) Cm[i] += sy.m0 ? sy.m0[i] : ((i / U == i % U) ? 1.0 : 0.0);
+    {
+      int piv[U];
+      lu_factor<U>(Cm, piv);
+      lu_solve<U, 1>(Cm, piv, sacc);
+    }
+    double l = a[RM];
+#pragma unroll
+    for (int d = 0; d < U; ++d) l -= a[RM + 1 + d] * sacc[d];
+    if (act) w.lampad[cb * RM + r] = l;
+    lamS[lane >> 4][r] = l;
+    double du[U];
+#pragma unroll
+    for (int aa = 0; aa < U; ++aa) {
+      double v = jur[aa] * l;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+      du[aa] = v;
+    }
+    unsigned long long eb = absbits(c0);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      const unsigned long long v = __shfl_xor(eb, o, 16);
+      eb = v > eb ? v : eb;
+    }
+    if (act && r == 0) {
+      double* q = (qsel ? w.qb : pick(sl.q, sp ^ 1)) + (size_t)c * sy.Q;
+      unsigned long long nb = 0ULL;
+#pragma unroll
+      for (int aa = 0; aa < U; ++aa) {
+        const double dq = metric_inv_u(sy, du, aa);  // delta_q = metric.inv @ delta_mu (:1033-1041, :1105-1113)
+        q[aa] -= dq;
+        const unsigned long long vb = absbits(dq);
+        nb = vb > nb ? vb : nb;
+      }
+      w.err[c] = bitsd(eb);
+      w.ndq[c] = nb;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (act && w.muF) {  // mu_F[m] = sum_i lambda_i LF[m][i] of the previous point's interval frames (KMuF)
+      const BlockDesc bd = sy.blk[b];
+      const double* lfb = pick(sl.LF, sp) + cb * sy.NOBS * RM * X;
+      double* mo = w.muF + cb * sy.NOBS * X;
+      const double* ls = lamS[lane >> 4];
+      for (int e = r; e < sy.NOBS * X; e += 16) {
+        const int m = e / X, ax = e - m * X;
+        double t = 0.0;
+        if (m < bd.nobs) {
+          for (int i = 0; i < RM; ++i)
+            if (i < bd.nrows) t += ls[i] * lfb[(m * RM + i) * X + ax];
+        }
+        mo[e] = t;
+      }
+    }
+  }
+}
+
 // The Newton-iteration sweep in two phases, for layouts with FEW, LONG blocks (SIR single block: B wavefronts of
 // k_newton_lean would each walk the whole chain, 300 us of pure latency per launch however few chains are active).
 // With the compact rows nothing in the hot loop depends on the adjoint rows, so the observation intervals of a block
@@ -1213,11 +1359,14 @@ __global__ void __launch_bounds__(64, CHMC_IVL_WAVES) k_newton_ivl(Sys sy, Slots
   }
 }
 
-template <class M, int RM, bool STATE = false>
+// FACTOR (Newton mode, one 16-row block per chain): the block's LU, Woodbury solve, multipliers and mu_F
+// (k_newton_factor_wave<.., FUSE>) follow in the same launch, fed from the LDS copies of the Gram block and the dc/du rows.
+template <class M, int RM, bool STATE = false, bool FACTOR = false>
 __global__ void __launch_bounds__(64) k_newton_comb(Sys sy, Slots sl, Work w, int which, int qsel) {
   constexpr int X = M::X, Z = M::Z, U = M::U, V0 = M::V0;
   constexpr int NI = CHMC_IVL_N(X, Z);
-  __shared__ double LamF[RM * X], LamN[RM * X], Dl[RM * RM], zl[RM * Z], Ys[RM * X], Iv[NI];
+  static_assert(!(STATE && FACTOR), "the factor step belongs to a Newton iteration");
+  __shared__ double LamF[RM * X], LamN[RM * X], Dl[RM * RM], zl[RM * Z], Ys[RM * X], Iv[NI], JuS[FACTOR ? RM * M::U : 1];
   const int lane = threadIdx.x & 63;
   const int wid = blockIdx.x;
   if (wid >= sy.B * sy.K) return;
@@ -1330,7 +1479,8 @@ __global__ void __launch_bounds__(64) k_newton_comb(Sys sy, Slots sl, Work w, in
       if (sy.noisy && i < bd.ny) v += sg_ * sigma_at(sy, pick(sl.q, sl_) + (size_t)c * sy.Q);  // dc_dn_l * dc_dn_r (:772-791)
       if (i >= bd.nrows) v = 1.0;
     }
-    w.Dw[cb * RM * RM + e] = v;
+    if constexpr (FACTOR) Dl[e] = v;
+    else w.Dw[cb * RM * RM + e] = v;
   }
   double G[Z * Z];
   M::gz_jac(q, G);
@@ -1347,10 +1497,15 @@ __global__ void __launch_bounds__(64) k_newton_comb(Sys sy, Slots sl, Work w, in
     } else {
       tt = i < bd.ny ? sigma_at(sy, q) * q[sy.U + sy.NV + bd.obs0 + i] : 0.0;
     }
-    (STATE ? pick(sl.JuP, sl_) : w.JuL)[cb * RM * U + e] = tt;
+    if constexpr (FACTOR) JuS[e] = tt;
+    else (STATE ? pick(sl.JuP, sl_) : w.JuL)[cb * RM * U + e] = tt;
   }
   if constexpr (STATE) {
     for (int e = lane; e < RM * Z; e += 64) w.zbP[cb * RM * Z + e] = zl[e];
+  }
+  if constexpr (FACTOR) {
+    lds_sync();
+    newton_factor16<M, RM, true>(sy, sl, w, which, qsel, c, b, lane < 16, Dl, JuS);
   }
 }
 
@@ -4143,148 +4298,14 @@ __global__ void __launch_bounds__(64) k_newton_fsm_wave(Sys sy, Slots sl, Work w
 // of k_solve_chain_wave<.., 0, 0> and KMuF<16, X, 0>, two launches of a latency-bound round less.
 template <class M, int RM, bool FUSE = false>
 __global__ void __launch_bounds__(64) k_newton_factor_wave(Sys sy, Slots sl, Work w, int prev, int qsel) {
-  static_assert(RM == 16, "rows over 16 lanes");
-  constexpr int U = M::U, NC = RM + 1 + U;  // augmented row: D row | c | dc/du row
-  const int lane = threadIdx.x & 63, r = lane & 15;
+  const int lane = threadIdx.x & 63;
   const int tid = blockIdx.x * 4 + (lane >> 4);
   const bool live = tid < sy.B * sy.K;
   const int tc = live ? tid : 0;
   const int c = tc / sy.K, b = tc - c * sy.K;
   const bool act = newton_select(w, c, prev, qsel) && live;
-  const int sp = sl.cur[c] ^ prev;
   const size_t cb = (size_t)c * sy.Kmax + b;
-  double a[NC];
-#pragma unroll
-  for (int k = 0; k < RM; ++k) a[k] = act ? w.Dw[cb * RM * RM + r * RM + k] : (k == r ? 1.0 : 0.0);
-  a[RM] = act ? w.cpad[cb * RM + r] : 0.0;
-  const double c0 = a[RM];  // the constraint value of this row (|c|_inf of the iterate, FUSE)
-#pragma unroll
-  for (int d = 0; d < U; ++d) a[RM + 1 + d] = act ? w.JuL[cb * RM * U + r * U + d] : 0.0;
-#pragma unroll
-  for (int j = 0; j < RM; ++j) {
-    // pivot: largest |a_ij| over the rows i >= j, the first one on ties
-    double best = r >= j ? fabs(a[j]) : -1.0;
-    int bi = r;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      const double ov = __shfl_xor(best, o, 16);
-      const int oi = __shfl_xor(bi, o, 16);
-      if (ov > best || (ov == best && oi < bi)) best = ov, bi = oi;
-    }
-    const int p = bi;  // (uniform over the 16 lanes of the block)
-    const int partner = r == j ? p : (r == p ? j : r);
-    double pr[NC];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) {
-      a[k] = __shfl(a[k], partner, 16);  // exchange rows j and p
-      pr[k] = __shfl(a[k], j, 16);       // the pivot row
-    }
-    const double inv = 1.0 / pr[j];
-    if (r > j) {
-      const double l = a[j] * inv;
-      a[j] = l;
-#pragma unroll
-      for (int k = j + 1; k < NC; ++k) a[k] -= l * pr[k];
-    }
-  }
-  // back substitution of the 1 + U right-hand sides, column by column
-#pragma unroll
-  for (int k = RM - 1; k >= 0; --k) {
-    const double ukk = __shfl(a[k], k, 16);
-#pragma unroll
-    for (int d = 0; d < 1 + U; ++d) {
-      const double xk = __shfl(a[RM + d], k, 16) / ukk;
-      if (r == k) a[RM + d] = xk;
-      if (r < k) a[RM + d] -= a[k] * xk;
-    }
-  }
-  if (act) {
-    w.tpad[cb * RM + r] = a[RM];
-#pragma unroll
-    for (int d = 0; d < U; ++d) w.Ew[cb * RM * U + r * U + d] = a[RM + 1 + d];
-  }
-  // C_b = Ju_prev^T E, s_b = Ju_prev^T t: sums over the 16 rows
-  double jur[U];
-#pragma unroll
-  for (int d = 0; d < U; ++d) jur[d] = act ? pick(sl.JuP, sp)[cb * RM * U + r * U + d] : 0.0;
-  double sacc[U], Cm[U * U];
-#pragma unroll
-  for (int aa = 0; aa < U; ++aa) {
-    double v = jur[aa] * a[RM];
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
-    if (!FUSE && act && r == 0) w.sb[cb * U + aa] = v;
-    sacc[aa] = v;
-#pragma unroll
-    for (int d = 0; d < U; ++d) {
-      double t = jur[aa] * a[RM + 1 + d];
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) t += __shfl_xor(t, o, 16);
-      if (!FUSE && act && r == 0) w.Cb[(cb * U + aa) * U + d] = t;
-      Cm[aa * U + d] = t;
-    }
-  }
-  if constexpr (FUSE) {
-    // (every lane of the block holds s = s_b and C_b: the core system C = M_0 + C_b, y = C^-1 s, redundantly per lane)
-    constexpr int X = M::X;
-    __shared__ double lamS[4][RM];
-#pragma unroll
-    for (int i = 0; i < U * U; ++i) Cm[i] += sy.m0 ? sy.m0[i] : ((i / U == i % U) ? 1.0 : 0.0);
-    {
-      int piv[U];
-      lu_factor<U>(Cm, piv);
-      lu_solve<U, 1>(Cm, piv, sacc);
-    }
-    double l = a[RM];
-#pragma unroll
-    for (int d = 0; d < U; ++d) l -= a[RM + 1 + d] * sacc[d];
-    if (act) w.lampad[cb * RM + r] = l;
-    lamS[lane >> 4][r] = l;
-    double du[U];
-#pragma unroll
-    for (int aa = 0; aa < U; ++aa) {
-      double v = jur[aa] * l;
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
-      du[aa] = v;
-    }
-    unsigned long long eb = absbits(c0);
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      const unsigned long long v = __shfl_xor(eb, o, 16);
-      eb = v > eb ? v : eb;
-    }
-    if (act && r == 0) {
-      double* q = (qsel ? w.qb : pick(sl.q, sp ^ 1)) + (size_t)c * sy.Q;
-      unsigned long long nb = 0ULL;
-#pragma unroll
-      for (int aa = 0; aa < U; ++aa) {
-        const double dq = metric_inv_u(sy, du, aa);  // delta_q = metric.inv @ delta_mu (:1033-1041, :1105-1113)
-        q[aa] -= dq;
-        const unsigned long long vb = absbits(dq);
-        nb = vb > nb ? vb : nb;
-      }
-      w.err[c] = bitsd(eb);
-      w.ndq[c] = nb;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    if (act && w.muF) {  // mu_F[m] = sum_i lambda_i LF[m][i] of the previous point's interval frames (KMuF)
-      const BlockDesc bd = sy.blk[b];
-      const double* lfb = pick(sl.LF, sp) + cb * sy.NOBS * RM * X;
-      double* mo = w.muF + cb * sy.NOBS * X;
-      const double* ls = lamS[lane >> 4];
-      for (int e = r; e < sy.NOBS * X; e += 16) {
-        const int m = e / X, ax = e - m * X;
-        double t = 0.0;
-        if (m < bd.nobs) {
-          for (int i = 0; i < RM; ++i)
-            if (i < bd.nrows) t += ls[i] * lfb[(m * RM + i) * X + ax];
-        }
-        mo[e] = t;
-      }
-    }
-  }
+  newton_factor16<M, RM, FUSE>(sy, sl, w, prev, qsel, c, b, act, w.Dw + cb * RM * RM, w.JuL + cb * RM * M::U);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
