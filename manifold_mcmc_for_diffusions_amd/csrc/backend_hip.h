@@ -81,6 +81,25 @@ static int poll_end(int slot) {
   note(hipEventSynchronize(g_poll_ev[slot]));
   return g_poll_host[slot];
 }
+// A per-chain functor launch whose LAST workgroup publishes a device counter (filled by the functor's atomics) straight into
+// the pinned poll slot: the count of a Newton round reaches the host without a copy packet behind the check (one launch
+// gap and a 4 us blit kernel less per round).  Every thread waits for its own atomics before the workgroup barrier; the
+// last workgroup (ticket) reads the finished counter with an atomic and stores it with system scope.
+template <class F>
+__global__ void __launch_bounds__(256) k_run_publish(F f, int n, int* counter, int* host_out, unsigned* ticket) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  if (tid < n) f(tid);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(ticket, 1u);
+    if (t == gridDim.x - 1) {
+      const int v = atomicAdd(counter, 0);
+      *ticket = 0u;
+      __hip_atomic_store(host_out, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
 static void d2d(void* dst, const void* src, size_t bytes) {
   note(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream));
 }
@@ -359,6 +378,34 @@ __global__ void __launch_bounds__(256) k_colmax(F f, int ncol) {
       if (v) atomicMax(tgt, v);
     }
   }
+}
+static thread_local unsigned* g_publish_ticket = nullptr;
+template <class F>
+static void launch_publish(F f, long n, int* counter, int poll_slot) {
+  if (n <= 0) return;
+  if (!g_poll_host) {
+    note(hipHostMalloc((void**)&g_poll_host, 4 * sizeof(int), hipHostMallocDefault));
+    for (int i = 0; i < 4; ++i) note(hipEventCreateWithFlags(&g_poll_ev[i], hipEventDisableTiming));
+  }
+  if (!g_publish_ticket) {
+    note(hipMalloc((void**)&g_publish_ticket, sizeof(unsigned)));
+    note(hipMemsetAsync(g_publish_ticket, 0, sizeof(unsigned), g_stream));
+  }
+  ProfRec r;
+  const bool prof = g_prof_on_for(0);
+  if (prof) {
+    r.a = prof_event(), r.b = prof_event(), r.cls = 0;
+    note(hipEventRecord(r.a, g_stream));
+  }
+  hipLaunchKernelGGL(k_run_publish<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, f, (int)n, counter,
+                     g_poll_host + poll_slot, g_publish_ticket);
+  note(hipGetLastError());
+  if (prof) {
+    note(hipEventRecord(r.b, g_stream));
+    g_prof_pending.push_back(r);
+    if (g_prof_pending.size() > 4096) prof_drain();
+  }
+  note(hipEventRecord(g_poll_ev[poll_slot], g_stream));
 }
 template <class F>
 static void launch_colmax(F f, int ncol, int B, int cls = 0) {

@@ -37,6 +37,12 @@ static void launch(F f, long n, int cls = 0) {
   (void)cls;
   for (long t = 0; t < n; ++t) f((int)t);
 }
+// (HIP: the last workgroup of the check publishes the round's count into the pinned poll slot; here: read it directly)
+template <class F>
+static void launch_publish(F f, long n, int* counter, int poll_slot) {
+  launch(f, n);
+  g_poll_val[poll_slot] = *counter;
+}
 template <class F>
 static void launch_rows(F f, int ncol, int B, int cls = 0) {
   (void)cls;
