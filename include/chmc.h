@@ -190,12 +190,23 @@ int chmc_switch_partition(chmc_ctx* ctx);
  * never writes the full rows of blocks with at most 8 rows.  The entry points below that return rows or multiply by them
  * rebuild the row-slot array first (one extra pass, only when called); results are the same to rounding.
  *
- * Environment switches (read when a context is created or at first use; each is exercised by a GPU test):
- *   CHMC_COMPACT_ROWS=0   round 1's stored-rows kernel family everywhere (the A/B partner of the default)
- *   CHMC_GRAM_MFMA=1      fp64-MFMA Gram kernel for 16-row blocks (on the stored-rows Newton sweep)
- *   CHMC_PAR_SCAN=0/1     time-parallel forward scan off / forced      CHMC_NO_FWD_SCAN=1  generic functor instead of the
- *   CHMC_HALVES=2         two overlapped half-batches per step           hand-scheduled forward scan
- *   CHMC_ASYNC=1          asynchronous per-chain-phase engine behind chmc_leapfrog_steps (read at every call) */
+ * Environment switches -- EVERY variable the library reads; each is exercised by a GPU test.  Defaults are chosen from the
+ * layout (blocks per chain, block length, rows) alone, never from the number of chains, so a chain's results do not depend
+ * on the shard it runs in (bitwise: tests/test_hip_parity.py::test_results_do_not_depend_on_the_shard_size).  Pinning a
+ * switch to a non-default value changes bits at the 1e-12 level (summation order, junction tolerance of the time-parallel
+ * scan: 3e-13 relative), never statuses.
+ *   read by chmc_create:
+ *   CHMC_COMPACT_ROWS=0     round 1's stored-rows kernel family everywhere (the A/B partner of the default)
+ *   CHMC_GRAM_MFMA=1        fp64-MFMA Gram kernel for 16-row blocks (on the stored-rows Newton sweep)
+ *   CHMC_PAR_SCAN=0/1       time-parallel forward scan off / forced (default: at most 4 blocks per chain, >= 1024 steps)
+ *   CHMC_PAR_WAVES=1/2/4    wavefronts per (chain, block) of that scan (default: from the block length; also read by the
+ *                           comparator target's scan at every call)
+ *   CHMC_ROW_SPLIT=1/2/4    16-row state evaluation: 1 = stored-rows sweeps, otherwise interval-parallel (default: <= 4 blocks)
+ *   CHMC_HALVES=2           two overlapped half-batches per step
+ *   read at every call:
+ *   CHMC_NO_FWD_SCAN=1      generic functor instead of the hand-scheduled forward scan
+ *   CHMC_RETRACT_KERNEL=0   one 16-row block per chain: lock-step Newton rounds instead of the per-chain retraction kernel
+ *   CHMC_ASYNC=1            asynchronous per-chain-phase engine behind chmc_leapfrog_steps */
 int chmc_constr(chmc_ctx* ctx, double* c);                                  /* :473-519, :1151-1155  [B][C] */
 /* :521-624, :1157-1161.  dc_du [B][C][U]; dc_dv [B][RM][NV] row-slot layout (slot i = row i of the block that
  * owns the column); dc/dn is sigma on observation rows (:601-608). */
@@ -293,7 +304,8 @@ int chmc_gather_samples(chmc_ctx* ctx, const void* local_dev, long count, void* 
 int chmc_comm_destroy(chmc_ctx* ctx);
 
 /* evaluation counters since creation: {constr, jacob_constr_blocks, lu_jacob_product_blocks, chol_gram_blocks,
- * grad_log_det_sqrt_gram, leapfrog_step calls, newton iteration launches, 0 (reserved)} (cf. _call_counts, :1451-1461).
+ * grad_log_det_sqrt_gram, leapfrog_step calls, newton rounds launched (a launch of the per-chain retraction kernel counts
+ * as one), 0 (reserved)} (cf. _call_counts, :1451-1461).
  * Host-side counts: the call does not touch the device. */
 int chmc_get_counters(const chmc_ctx* ctx, long long* out8);
 
@@ -302,7 +314,8 @@ int chmc_get_counters(const chmc_ctx* ctx, long long* out8);
  *   out80[1 .. 63] histogram of sweeps to convergence of the time-parallel scan (1 + sweeps + 16 (guess kind - 1)), [15] parked
  *   out80[64]      launches of the fp64-MFMA Gram kernel (v_mfma_f64_16x16x4_f64; 16-row blocks, CHMC_GRAM_MFMA=1)
  *   out80[65]      launches of the vector-FMA Gram kernel over stored rows (16-row blocks)
- *   out80[66 .. 79] reserved (0)
+ *   out80[66]      launches of the per-chain retraction kernel (k_retract_chain: one 16-row block per chain)
+ *   out80[67 .. 79] reserved (0)
  * Synchronises the context's stream. */
 int chmc_get_diagnostics(chmc_ctx* ctx, long long* out80);
 

@@ -403,7 +403,8 @@ class ChmcContext:
         out = (C.c_longlong * 80)()
         check(self.L.chmc_get_diagnostics(self.h, out), "chmc_get_diagnostics")
         v = np.array(out[:], dtype=np.int64)
-        return dict(par_scan=v[:64], gram_mfma_launches=int(v[64]), gram_valu_launches=int(v[65]))
+        return dict(par_scan=v[:64], gram_mfma_launches=int(v[64]), gram_valu_launches=int(v[65]),
+                    retract_kernel_launches=int(v[66]))
 
     def counters(self):
         out = (C.c_longlong * 8)()

@@ -379,6 +379,10 @@ __global__ void __launch_bounds__(256) k_colmax(F f, int ncol) {
     }
   }
 }
+// One ticket word per poll slot: the check kernels of the two half-batches (CHMC_HALVES=2: slots 2 h + (round & 1)) run on
+// different streams and may overlap, so they must not draw tickets from one counter (a workgroup of the wrong launch would
+// then publish a partial count and the other half's count would never arrive).  Launches that share a slot are ordered by
+// their stream.  The words are zeroed synchronously when they are allocated and reset by every launch's last workgroup.
 static thread_local unsigned* g_publish_ticket = nullptr;
 template <class F>
 static void launch_publish(F f, long n, int* counter, int poll_slot) {
@@ -388,8 +392,8 @@ static void launch_publish(F f, long n, int* counter, int poll_slot) {
     for (int i = 0; i < 4; ++i) note(hipEventCreateWithFlags(&g_poll_ev[i], hipEventDisableTiming));
   }
   if (!g_publish_ticket) {
-    note(hipMalloc((void**)&g_publish_ticket, sizeof(unsigned)));
-    note(hipMemsetAsync(g_publish_ticket, 0, sizeof(unsigned), g_stream));
+    note(hipMalloc((void**)&g_publish_ticket, 4 * sizeof(unsigned)));
+    note(hipMemset(g_publish_ticket, 0, 4 * sizeof(unsigned)));
   }
   ProfRec r;
   const bool prof = g_prof_on_for(0);
@@ -398,7 +402,7 @@ static void launch_publish(F f, long n, int* counter, int poll_slot) {
     note(hipEventRecord(r.a, g_stream));
   }
   hipLaunchKernelGGL(k_run_publish<F>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, g_stream, f, (int)n, counter,
-                     g_poll_host + poll_slot, g_publish_ticket);
+                     g_poll_host + poll_slot, g_publish_ticket + poll_slot);
   note(hipGetLastError());
   if (prof) {
     note(hipEventRecord(r.b, g_stream));

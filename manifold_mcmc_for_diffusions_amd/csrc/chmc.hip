@@ -8,4 +8,5 @@
 #define CHMC_WAVE_KERNELS 1
 #include "chmc_core.h"
 #include "chmc_wave.h"
+#include "chmc_retract.h"
 #include "chmc_api.inc"

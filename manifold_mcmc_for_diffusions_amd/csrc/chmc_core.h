@@ -1927,6 +1927,21 @@ struct KNewtonBegin {
   }
 };
 
+// After the last round the host enqueued: a chain that is STILL in the loop (the host stopped on a stale or wrong count, or
+// ran out of rounds with a carried-over time-parallel scan) must not pass as converged -- KNewtonBegin left its projection
+// status at 0.  It is reported as "did not converge" (:1393-1402) with the iterations it has done.
+struct KNewtonEnd {
+  Work w;
+  int* iters_dst;
+  CHMC_HD void operator()(int c) const {
+    if (!w.nw[c]) return;
+    w.nw[c] = 0;
+    w.nstat[c] = 1;
+    w.ok[c] = 0, w.status[c] = 1;
+    if (iters_dst) iters_dst[c] += w.iters[c];
+  }
+};
+
 // J w, one work item per (chain, block, row) (lmult_by_jacob_constr :822-877); input vector selected by
 // vsel (0: slot p, 1: work.pb, 2: work.vin); result in work.cpad
 template <int RM>

@@ -1224,18 +1224,13 @@ __device__ __forceinline__ void newton_factor16(const Sys& sy, const Slots& sl, 
 // STATE (both phases): the state evaluation of slot `which` in the same two phases (k_newton_lean<.., STATE> for blocks of
 // any RM <= 16): phase A also WRITES the compact rows PB[s] = T_s and sums T_s T_s^T; phase B writes the frames LF[m], the
 // symmetric Gram block, the rows' v_0 columns, the dc/du rows of the slot and the dc/dz rows (work.zbP).
-template <class M, bool STATE = false>
-__global__ void __launch_bounds__(64, CHMC_IVL_WAVES) k_newton_ivl(Sys sy, Slots sl, Work w, int which, int qsel) {
+// newton_ivl_body: the sums of observation interval m of block (c, b) by the calling wavefront (which / qsel already
+// resolved for the chain; m < nobs of the block); shared by k_newton_ivl and the per-chain retraction kernel.
+template <class M, bool STATE>
+__device__ __forceinline__ void newton_ivl_body(const Sys& sy, const Slots& sl, const Work& w, int which, int qsel, int c, int b,
+                                                int m, const BlockDesc& bd) {
   constexpr int X = M::X, V = M::V, Z = M::Z;
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x;
-  if (wid >= sy.B * sy.K * sy.NOBS) return;
-  const int m = wid % sy.NOBS;
-  const int cbi = sy.order[wid / sy.NOBS];
-  const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (STATE ? !w.ok[c] : !newton_select(w, c, which, qsel)) return;
-  const BlockDesc bd = sy.blk[b];
-  if (m >= bd.nobs) return;
   const int sl_ = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
   const int S = sy.S;
@@ -1358,22 +1353,31 @@ __global__ void __launch_bounds__(64, CHMC_IVL_WAVES) k_newton_ivl(Sys sy, Slots
     for (int i = 0; i < X * X; ++i) out[X * X + X * Z + i] = Pf[i];
   }
 }
+template <class M, bool STATE = false>
+__global__ void __launch_bounds__(64, CHMC_IVL_WAVES) k_newton_ivl(Sys sy, Slots sl, Work w, int which, int qsel) {
+  const int wid = blockIdx.x;
+  if (wid >= sy.B * sy.K * sy.NOBS) return;
+  const int m = wid % sy.NOBS;
+  const int cbi = sy.order[wid / sy.NOBS];
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (STATE ? !w.ok[c] : !newton_select(w, c, which, qsel)) return;
+  const BlockDesc bd = sy.blk[b];
+  if (m >= bd.nobs) return;
+  newton_ivl_body<M, STATE>(sy, sl, w, which, qsel, c, b, m, bd);
+}
 
 // FACTOR (Newton mode, one 16-row block per chain): the block's LU, Woodbury solve, multipliers and mu_F
 // (k_newton_factor_wave<.., FUSE>) follow in the same launch, fed from the LDS copies of the Gram block and the dc/du rows.
-template <class M, int RM, bool STATE = false, bool FACTOR = false>
-__global__ void __launch_bounds__(64) k_newton_comb(Sys sy, Slots sl, Work w, int which, int qsel) {
+// newton_comb_body: the combine step of block (c, b) by ONE wavefront (which / qsel already resolved for the chain); its LDS
+// arrays serve one wavefront per workgroup.  Shared by k_newton_comb and the per-chain retraction kernel.
+template <class M, int RM, bool STATE, bool FACTOR>
+__device__ __forceinline__ void newton_comb_body(const Sys& sy, const Slots& sl, const Work& w, int which, int qsel, int c, int b,
+                                                 const BlockDesc& bd) {
   constexpr int X = M::X, Z = M::Z, U = M::U, V0 = M::V0;
   constexpr int NI = CHMC_IVL_N(X, Z);
   static_assert(!(STATE && FACTOR), "the factor step belongs to a Newton iteration");
   __shared__ double LamF[RM * X], LamN[RM * X], Dl[RM * RM], zl[RM * Z], Ys[RM * X], Iv[NI], JuS[FACTOR ? RM * M::U : 1];
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x;
-  if (wid >= sy.B * sy.K) return;
-  const int cbi = sy.order[wid];
-  const int c = cbi / sy.K, b = cbi - c * sy.K;
-  if (STATE ? !w.ok[c] : !newton_select(w, c, which, qsel)) return;
-  const BlockDesc bd = sy.blk[b];
   const int sl_ = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
   const int S = sy.S, NV = sy.NV;
@@ -1507,6 +1511,16 @@ __global__ void __launch_bounds__(64) k_newton_comb(Sys sy, Slots sl, Work w, in
     lds_sync();
     newton_factor16<M, RM, true>(sy, sl, w, which, qsel, c, b, lane < 16, Dl, JuS);
   }
+}
+template <class M, int RM, bool STATE = false, bool FACTOR = false>
+__global__ void __launch_bounds__(64) k_newton_comb(Sys sy, Slots sl, Work w, int which, int qsel) {
+  const int wid = blockIdx.x;
+  if (wid >= sy.B * sy.K) return;
+  const int cbi = sy.order[wid];
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  if (STATE ? !w.ok[c] : !newton_select(w, c, which, qsel)) return;
+  const BlockDesc bd = sy.blk[b];
+  newton_comb_body<M, RM, STATE, FACTOR>(sy, sl, w, which, qsel, c, b, bd);
 }
 
 // Reverse sweep for 16-row blocks with the row-indexed state in LDS (see k_gld_bwd_wave_ldsrows: at 16 rows the fully
@@ -4734,23 +4748,6 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
 // W wavefronts per (chain, block): 64 W segments, the affine prefix scan continued across the wavefronts through LDS (three
 // workgroup barriers per sweep).  The host picks W so that the launch has about one wavefront per SIMD of the chip
 // (chmc_create: par_waves); W = 1 compiles to the single-wavefront kernel (no LDS, no barrier).
-template <class M, int RM, int W>
-__global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, int which, int qsel, int use_nw,
-                                                    int store_traj, int gsel, int round) {
-  // (ii) makes the sweeps exact after at most 64 of them, but a block that is not settled after a dozen belongs to a
-  // chain whose retraction is diverging (healthy blocks settle in 2-9 sweeps): it is handed to the sequential
-  // recursion, which costs the same 0.9 ms as the remaining sweeps would
-  constexpr int X = M::X, V = M::V;
-  // Inside a Newton loop (lock-step: use_nw == 1; asynchronous engine: use_nw == 3) with ONE block per chain a scan that has
-  // not settled after CHMC_PAR_MAXS_ROUND sweeps is neither integrated sequentially nor handed to another stream: its
-  // junction states are kept in the trajectory buffer, the chain's mask becomes 2 -- the round's other kernels and the
-  // convergence check skip it, it takes no iteration -- and the next round's launch goes on sweeping from there.  A launch
-  // therefore never lasts longer than CHMC_PAR_MAXS_ROUND sweeps (99.8 % of the scans settle within 6, tools/
-  // par_scan_stats.py), and nothing is handed to another stream: round 2's scheme (12 sweeps, then the chain parked for a
-  // 0.9 ms sequential scan on a side stream, re-joining three rounds later) cost boarding-school SIR at 256 chains
-  // 22.7 k against 26.3 k steps/s (DESIGN.md section 4).
-  // (With several blocks per chain the chain's mask would be shared by wavefronts that settle and wavefronts that do not:
-  // those layouts keep 12 sweeps and the sequential recursion inside the launch, as outside a loop.)
 // Junction tolerance (relative to max(|x|, 1)): a junction has settled when its new start state moved by no more than this.
 // Measured on boarding-school SIR, 256 chains, against the sequential scan over 12 288 chain-steps (tools/par_scan_compare.py,
 // step sizes 0.25 and 0.4): 1e-13: 47.2 k steps/s, statuses equal, 6 iteration counts differ, positions to 2.3e-13;
@@ -4763,9 +4760,16 @@ __global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, in
 #ifndef CHMC_PAR_MAXS_ROUND
 #define CHMC_PAR_MAXS_ROUND 12  // measured at 256 boarding-school SIR chains: 4: 22.5 k, 6: 25.0 k, 8: 25.9 k, 10: 26.1 k, 12: 26.3 k, 16: 25.7 k steps/s
 #endif
-  const bool async = use_nw == 3;
-  const bool apend = (async || use_nw == 1) && sy.K == 1;
-  const int MAXS = apend ? CHMC_PAR_MAXS_ROUND : 12;
+// The sweeps of the time-parallel scan of block `bd` of one chain by the W wavefronts of the calling workgroup (all of them
+// must call it: workgroup barriers inside when W > 1): position `q`, trajectory written to `traj`, start states taken from
+// `guess`, constraint values to `out`.  Returns whether every junction settled within MAXS sweeps (the same value in every
+// thread); Ul / s0r / haver: this lane's segment start state, first step and whether it owns a segment (for a caller that
+// keeps the junction states of an unsettled scan).  Shared by k_fwd_par and the per-chain retraction kernel (chmc_retract.h).
+template <class M, int RM, int W>
+__device__ __forceinline__ bool fwd_par_sweeps(const Sys& sy, const Work& w, const BlockDesc& bd, const double* q,
+                                               const double* xobs, double* traj, const double* guess, double* out, int MAXS,
+                                               int gsel, double (&Ul)[M::X], int& s0r, bool& haver) {
+  constexpr int X = M::X, V = M::V;
   const int lane = threadIdx.x & 63;
   const int wv = W > 1 ? (int)(threadIdx.x >> 6) : 0;  // wavefront of the workgroup
   const int gl = W > 1 ? (int)threadIdx.x : lane;      // segment of the block
@@ -4776,43 +4780,9 @@ __global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, in
       sUn[W > 1 ? W : 1][M::X];
   __shared__ int sFlag[W > 1 ? W : 1], sFront[W > 1 ? W : 1][1 + 2 * M::X];
   __shared__ double sTv[W > 1 ? W : 1][M::X];
-  const int wid = blockIdx.x;
-  if (wid >= sy.B * sy.K) return;
-  const int cbi = sy.order[wid];
-  const int c = cbi / sy.K, b = cbi - c * sy.K;
-  int* amask = nullptr;  // async: the mask entry of this chain's retraction
-  if (async) {
-    const int f = w.nw[c], r = w.nw2[c];
-    if (r == 1 || r == 2) {
-      amask = w.nw2 + c, which = 0, qsel = 1;
-    } else if (f == 1 || f == 2) {
-      amask = w.nw + c, which = 1, qsel = 0;
-    } else {
-      return;
-    }
-    gsel = (*amask == 2 || w.iters[c] > 0) ? 1 : 2;  // own previous sweeps / previous iterate; first iteration: the state's trajectory
-  } else if (use_nw) {
-    const int f = w.nw[c];
-    if (f != 1 && !(apend && f == 2)) return;
-    if (apend) {
-      amask = w.nw + c;
-      if (f == 2) gsel = 1;  // carry on from the junction states kept by the previous round's launch
-    }
-  } else if (!w.ok[c]) {
-    return;
-  }
-  (void)round;
-  const BlockDesc bd = sy.blk[b];
-  const int s_ = sl.cur[c] ^ which;
   const int S = sy.S, L = bd.nsteps;
-  const double* q = (qsel ? w.qb : pick(sl.q, s_)) + (size_t)c * sy.Q;
-  const double* xobs = sy.xobs + (size_t)c * sy.T * X;
-  const size_t toff = (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
-  double* traj = (store_traj == 2 ? w.trajw : pick(sl.traj, s_)) + toff;
-  const double* guess = gsel == 2 ? pick(sl.traj, sl.cur[c]) + toff : gsel == 3 ? w.trajw + toff : traj;
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
   const double* nn = q + sy.U + sy.NV;
-  double* out = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
   ChainConsts<M> cc;
   cc.init(q, sy.dl);
   const double sig = sy.noisy ? sigma_at(sy, q) : 0.0;
@@ -4826,7 +4796,6 @@ __global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, in
   const int m = (L + NSEG - 1) / NSEG;                    // steps per segment
   const int s0 = gl * m, s1 = (s0 + m < L ? s0 + m : L);  // this lane's segment [s0, s1) (empty when s0 >= L)
   const bool have = s0 < L;
-  double Ul[X];  // start state of this lane's segment
 #pragma unroll
   for (int a = 0; a < X; ++a) Ul[a] = gl == 0 ? x0[a] : (have ? guess[(size_t)s0 * X + a] : 0.0);
   bool converged = false;
@@ -5086,6 +5055,70 @@ __global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, in
     }
     if (converged && gl == 0 && w.nfallback) atomicAdd(w.nfallback + 1 + (sweep < 14 ? sweep : 14) + 16 * (gsel - 1), 1);
   }
+  s0r = s0, haver = have;
+  return converged;
+}
+
+template <class M, int RM, int W>
+__global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, int which, int qsel, int use_nw,
+                                                    int store_traj, int gsel, int round) {
+  // (ii) makes the sweeps exact after at most 64 of them, but a block that is not settled after a dozen belongs to a
+  // chain whose retraction is diverging (healthy blocks settle in 2-9 sweeps): it is handed to the sequential
+  // recursion, which costs the same 0.9 ms as the remaining sweeps would
+  constexpr int X = M::X, V = M::V;
+  // Inside a Newton loop (lock-step: use_nw == 1; asynchronous engine: use_nw == 3) with ONE block per chain a scan that has
+  // not settled after CHMC_PAR_MAXS_ROUND sweeps is neither integrated sequentially nor handed to another stream: its
+  // junction states are kept in the trajectory buffer, the chain's mask becomes 2 -- the round's other kernels and the
+  // convergence check skip it, it takes no iteration -- and the next round's launch goes on sweeping from there.  A launch
+  // therefore never lasts longer than CHMC_PAR_MAXS_ROUND sweeps (99.8 % of the scans settle within 6, tools/
+  // par_scan_stats.py), and nothing is handed to another stream: round 2's scheme (12 sweeps, then the chain parked for a
+  // 0.9 ms sequential scan on a side stream, re-joining three rounds later) cost boarding-school SIR at 256 chains
+  // 22.7 k against 26.3 k steps/s (DESIGN.md section 4).
+  // (With several blocks per chain the chain's mask would be shared by wavefronts that settle and wavefronts that do not:
+  // those layouts keep 12 sweeps and the sequential recursion inside the launch, as outside a loop.)
+  const bool async = use_nw == 3;
+  const bool apend = (async || use_nw == 1) && sy.K == 1;
+  const int MAXS = apend ? CHMC_PAR_MAXS_ROUND : 12;
+  const int gl = W > 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);  // segment of the block
+  const int wid = blockIdx.x;
+  if (wid >= sy.B * sy.K) return;
+  const int cbi = sy.order[wid];
+  const int c = cbi / sy.K, b = cbi - c * sy.K;
+  int* amask = nullptr;  // async: the mask entry of this chain's retraction
+  if (async) {
+    const int f = w.nw[c], r = w.nw2[c];
+    if (r == 1 || r == 2) {
+      amask = w.nw2 + c, which = 0, qsel = 1;
+    } else if (f == 1 || f == 2) {
+      amask = w.nw + c, which = 1, qsel = 0;
+    } else {
+      return;
+    }
+    gsel = (*amask == 2 || w.iters[c] > 0) ? 1 : 2;  // own previous sweeps / previous iterate; first iteration: the state's trajectory
+  } else if (use_nw) {
+    const int f = w.nw[c];
+    if (f != 1 && !(apend && f == 2)) return;
+    if (apend) {
+      amask = w.nw + c;
+      if (f == 2) gsel = 1;  // carry on from the junction states kept by the previous round's launch
+    }
+  } else if (!w.ok[c]) {
+    return;
+  }
+  (void)round;
+  const BlockDesc bd = sy.blk[b];
+  const int s_ = sl.cur[c] ^ which;
+  const int S = sy.S, L = bd.nsteps;
+  const double* q = (qsel ? w.qb : pick(sl.q, s_)) + (size_t)c * sy.Q;
+  const double* xobs = sy.xobs + (size_t)c * sy.T * X;
+  const size_t toff = (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  double* traj = (store_traj == 2 ? w.trajw : pick(sl.traj, s_)) + toff;
+  const double* guess = gsel == 2 ? pick(sl.traj, sl.cur[c]) + toff : gsel == 3 ? w.trajw + toff : traj;
+  double* out = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
+  double Ul[X];  // start state of this lane's segment
+  int s0 = 0;
+  bool have = false;
+  const bool converged = fwd_par_sweeps<M, RM, W>(sy, w, bd, q, xobs, traj, guess, out, MAXS, gsel, Ul, s0, have);
   if (apend) {
     if (!converged) {
       // keep the junction states for the next round's sweeps (the guess is then this buffer: gsel 1)
@@ -5102,9 +5135,18 @@ __global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, in
     if (gl == 0) *amask = 1;
   }
   if (!converged && gl == 0) {  // sequential recursion (same arithmetic as fwd_block_impl)
+    const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+    const double* nn = q + sy.U + sy.NV;
+    ChainConsts<M> cc;
+    cc.init(q, sy.dl);
+    const double sig = sy.noisy ? sigma_at(sy, q) : 0.0;
     double x[X], xn[X];
+    if (bd.first) {
+      M::gx0(cc.z, q + sy.U, x);
+    } else {
 #pragma unroll
-    for (int a = 0; a < X; ++a) x[a] = x0[a];
+      for (int a = 0; a < X; ++a) x[a] = xobs[(bd.obs0 - 1) * X + a];
+    }
     for (int s = 0; s < L; ++s) {
 #pragma unroll
       for (int a = 0; a < X; ++a) traj[(size_t)s * X + a] = x[a];

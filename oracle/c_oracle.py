@@ -104,6 +104,8 @@ def _load(path):
         L.orc_chain_step.restype = C.c_int
         L.orc_chain_step.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                      C.c_int, C.c_double, ip, ip, dp]
+        L.orc_chain_trace.restype = C.c_int
+        L.orc_chain_trace.argtypes = [C.c_void_p, C.c_int, dp, dp]
     return L
 
 
@@ -262,3 +264,11 @@ class OracleChain:
         st = self.L.orc_chain_step(self.h, dt, n_inner, int(newton), ctol, ptol, dtol, max_iters, rev_tol,
                                    C.byref(itf), C.byref(itb), C.byref(rev))
         return st, itf.value, itb.value, rev.value
+
+    def trace(self, direction):
+        """Per-iteration (|c|_inf of the iterate, |delta q|_inf of its update) of the forward (0) / reverse (1) retraction
+        of the last step: entry k holds what the loop condition (sde/mici_extensions.py:1119-1127) saw after k + 1
+        iterations."""
+        err, ndq = np.zeros(64), np.zeros(64)
+        n = self.L.orc_chain_trace(self.h, int(direction), _d(err), _d(ndq))
+        return err[:n].copy(), ndq[:n].copy()

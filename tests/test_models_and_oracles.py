@@ -232,3 +232,27 @@ def test_c_oracle_block_metric_against_dense_algebra(model, T, S, R, noisy):
     osy.set_metric(None)
     with pytest.raises(ValueError):
         make_case("fhn", 6, 4, 2, True, B=1, seed=1, gaussian=True)["osys"].set_metric(M0)
+
+
+def test_oracle_projection_trace_matches_the_loop_condition():
+    """OracleChain.trace (the per-iteration |c|_inf, |delta q|_inf the GPU parity tests consult when an iteration count
+    differs): one entry per iteration, the loop condition (sde/mici_extensions.py:1119-1127) holds at the last entry of a
+    converged retraction and at no earlier one; a count may only be excused where the disputed entry sits on a tolerance."""
+    from test_hip_parity import _count_differs_on_tolerance_edge
+    case = make_case("sir", 6, 8, 2, True, B=1, seed=11)
+    osy, rng = case["osys"], case["rng"]
+    ch = c_oracle.OracleChain(osy)
+    ch.set(case["q"][0], rng.standard_normal(osy.Q), case["x_obs"][0], 0)
+    ch.project_mom()
+    st, itf, itb, _ = ch.step(0.05)
+    assert st == 0
+    for d, it in ((0, itf), (1, itb)):
+        err, ndq = ch.trace(d)
+        assert len(err) == it == len(ndq)
+        ok = (err < 1e-9) & (ndq < 1e-8)
+        assert ok[-1] and not ok[:-1].any()
+        # far from the tolerances: no other count can be excused
+        assert not _count_differs_on_tolerance_edge(ch, d, it - 1, it)
+        # the same trace judged with a tolerance placed on the deciding quantity is an edge
+        k = it - 1
+        assert _count_differs_on_tolerance_edge(ch, d, k, it, ctol=max(err[k - 1], 1e-300) * 1.001, ptol=1.0)
