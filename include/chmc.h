@@ -193,8 +193,8 @@ int chmc_switch_partition(chmc_ctx* ctx);
  * Environment switches -- EVERY variable the library reads; each is exercised by a GPU test.  Defaults are chosen from the
  * layout (blocks per chain, block length, rows) alone, never from the number of chains, so a chain's results do not depend
  * on the shard it runs in (bitwise: tests/test_hip_parity.py::test_results_do_not_depend_on_the_shard_size).  Pinning a
- * switch to a non-default value changes bits at the 1e-12 level (summation order, junction tolerance of the time-parallel
- * scan: 3e-13 relative), never statuses.
+ * switch to a non-default value changes bits at the rounding level (summation order; the time-parallel scan equals the
+ * sequential recursion to about 1e-15 relative after its final sweep, not bitwise), never statuses.
  *   read by chmc_create:
  *   CHMC_COMPACT_ROWS=0     round 1's stored-rows kernel family everywhere (the A/B partner of the default)
  *   CHMC_GRAM_MFMA=1        fp64-MFMA Gram kernel for 16-row blocks (on the stored-rows Newton sweep)

@@ -10,7 +10,7 @@
 // wavefronts of one chain:
 //     scan       time-parallel multiple shooting over 64 NW segments          fwd_par_sweeps<M, RM, NW>   (all wavefronts)
 //     sums       one wavefront per observation interval                       newton_ivl_body             (wavefront m mod NW)
-//     combine    frames, Gram block, LU, core system, multipliers, mu_F       newton_comb_body<.., FACTOR> (wavefront 0)
+//     combine    frames, Gram block, LU, core system, multipliers, mu_F       newton_comb_wg (all threads; LU: wavefront 0)
 //     update     q_v -= mu_F[m] . PB[s], max |delta q|                        KUpdatePB (functor, all threads)
 //     check      the loop condition (:1119-1127), status mapping (:1462-1476) one thread
 // so the workgroup walks them with workgroup barriers instead of launches, the phases hand their results on through the
@@ -31,9 +31,159 @@ namespace chmc {
 #define CHMC_RETRACT_WAVES 8  // 512 threads: two wavefronts per SIMD of the chain's CU, up to 256 registers each
 #endif
 
+// -DCHMC_RETRACT_PROF: thread 0 of every workgroup adds the 100 MHz ticks of each phase to work.nfallback[48 ..] (diagnostic
+// build only, tools/retract_prof.py): [48] scan [49] sums [50] combine [51] update + check [52] iterations [53] retractions
+#ifdef CHMC_RETRACT_PROF
+#define CHMC_RPROF(slot)                                                   \
+  do {                                                                     \
+    if (tid == 0) {                                                        \
+      const long long t1_ = wall_clock64();                                \
+      atomicAdd(w.nfallback + (slot), (int)(t1_ - t0_));                   \
+      t0_ = t1_;                                                           \
+    }                                                                      \
+  } while (0)
+#else
+#define CHMC_RPROF(slot) \
+  do {                   \
+  } while (0)
+#endif
+
 __device__ __forceinline__ void wg_phase_sync() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
+}
+
+// The combine step of a Newton iteration (newton_comb_body<.., FACTOR>) by the whole workgroup: the per-interval frames no
+// longer walk the intervals one after the other with everything in one wavefront (14 intervals x 5 LDS round trips) --
+//   (a) the interval sums and the previous point's frames go to LDS;
+//   (b) one thread per row carries its adjoint row back through the interval products Pt[m] and leaves the frame LamF[m][i]
+//       of every interval (the only sequential part: nobs vector-matrix products of size X);
+//   (c) Ys[m][j] = Ss[m] LFprev[m][j]^T for every (m, j);  (d) the Gram block D[i][j] = sum_m LamF[m][i] . Ys[m][j] and the
+//       dc/dz rows sum_m LamF[m][i] Ws[m], one thread per entry, m descending and the components ascending as in
+//       newton_comb_body (same sums, same order);  (e) v_0 columns, observation-noise diagonal, identity padding, dc/du rows;
+//   (f) the block's LU, the chain's core system, the multipliers and mu_F on 16 lanes of wavefront 0 (newton_factor16).
+template <class M, int RM, int NW>
+__device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, const Work& w, int prev, int qsel, int c,
+                                               const BlockDesc& bd) {
+  constexpr int X = M::X, Z = M::Z, U = M::U, V0 = M::V0, NT = 64 * NW;
+  constexpr int NI = CHMC_IVL_N(X, Z);
+  constexpr int MO = RM;  // observation intervals of a block with at most RM rows
+  __shared__ double Iv[MO][NI], LFp[MO][RM * X], LamF[MO + 1][RM * X], Ys[MO][RM * X], Dl[RM * RM], zl[RM * Z], JuS[RM * U];
+  const int tid = threadIdx.x;
+  const int sp = sl.cur[c] ^ prev;
+  const size_t cb = (size_t)c * sy.Kmax;
+  const int S = sy.S, NV = sy.NV, nobs = bd.nobs;
+  const double* q = (qsel ? w.qb : pick(sl.q, sp ^ 1)) + (size_t)c * sy.Q;
+  const double* traj = w.trajw + (size_t)c * sy.TRJ + (size_t)bd.step0 * X;
+  const double* Jr = pick(sl.Jv, sp) + (size_t)c * RM * NV;
+  const double* LFr = pick(sl.LF, sp) + cb * sy.NOBS * RM * X;
+  // (a)
+  for (int e = tid; e < nobs * NI; e += NT) Iv[e / NI][e % NI] = w.ivl[cb * sy.NOBS * NI + e];
+  for (int e = tid; e < nobs * RM * X; e += NT) LFp[e / (RM * X)][e % (RM * X)] = LFr[e];
+  __syncthreads();
+  // (b) thread i: the adjoint row i from the end of the block back to its start; LamF[m] = the rows at the END of
+  // interval m (after the rows that start there have been injected), LamF[MO] = the rows at the block's start
+  if (tid < RM) {
+    const int i = tid;
+    double row[X];
+#pragma unroll
+    for (int a = 0; a < X; ++a) row[a] = 0.0;
+    for (int m = nobs - 1; m >= 0; --m) {
+      if (m < bd.ny && i == m) M::obs_grad(traj + (size_t)(m + 1) * S * X, row);
+      if (m == nobs - 1 && !bd.last && i >= bd.ny && i < bd.ny + X) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) row[a] = (a == i - bd.ny) ? 1.0 : row[a];
+      }
+#pragma unroll
+      for (int a = 0; a < X; ++a) LamF[m][i * X + a] = row[a];
+      double nr[X];
+#pragma unroll
+      for (int d = 0; d < X; ++d) {
+        double tt = 0.0;
+#pragma unroll
+        for (int a = 0; a < X; ++a) tt += row[a] * Iv[m][X * X + X * Z + a * X + d];
+        nr[d] = tt;
+      }
+#pragma unroll
+      for (int a = 0; a < X; ++a) row[a] = nr[a];
+    }
+#pragma unroll
+    for (int a = 0; a < X; ++a) LamF[MO][i * X + a] = row[a];
+  }
+  // (c)
+  for (int e = tid; e < nobs * RM * X; e += NT) {
+    const int m = e / (RM * X), r = e - m * RM * X;
+    const int jj = r / X, a = r - jj * X;
+    double tt = 0.0;
+#pragma unroll
+    for (int a2 = 0; a2 < X; ++a2) tt += Iv[m][a * X + a2] * LFp[m][jj * X + a2];
+    Ys[m][r] = tt;
+  }
+  __syncthreads();
+  // (d) + (e)
+  if (tid < RM * RM) {
+    const int i = tid / RM, jj = tid - i * RM;
+    double tt = 0.0;
+    for (int m = nobs - 1; m >= 0; --m) {
+#pragma unroll
+      for (int a = 0; a < X; ++a) tt += LamF[m][i * X + a] * Ys[m][jj * X + a];
+    }
+    if (bd.first) {  // x_0 = generate_x_0(z, v_0): the v_0 columns against the previous point's stored v_0 columns
+      double dz[X * Z], dv0[X * V0];
+      M::gx0_jac(dz, dv0);
+      for (int d = 0; d < V0; ++d) {
+        double j0 = 0.0;
+        for (int a = 0; a < X; ++a) j0 += LamF[MO][i * X + a] * dv0[a * V0 + d];
+        tt += j0 * Jr[(size_t)jj * NV + d];
+      }
+    }
+    if (i == jj) {  // noise term on the observation rows (dc_dn_l * dc_dn_r, :772-791), identity padding
+      const double sg_ = sy.noisy ? sigma_at(sy, q) : 0.0;
+      if (sy.noisy && i < bd.ny) tt += sg_ * sigma_at(sy, pick(sl.q, sp) + (size_t)c * sy.Q);
+      if (i >= bd.nrows) tt = 1.0;
+    }
+    Dl[tid] = tt;
+  } else if (tid < RM * RM + RM * Z) {
+    const int e = tid - RM * RM;
+    const int i = e / Z, mz = e - i * Z;
+    double tt = 0.0;
+    for (int m = nobs - 1; m >= 0; --m) {
+#pragma unroll
+      for (int a = 0; a < X; ++a) tt += LamF[m][i * X + a] * Iv[m][X * X + a * Z + mz];
+    }
+    if (bd.first) {
+      double dz[X * Z], dv0[X * V0];
+      M::gx0_jac(dz, dv0);
+      for (int a = 0; a < X; ++a) {
+        double dzs = 0.0;
+#pragma unroll
+        for (int ee = 0; ee < X * Z; ++ee) dzs = ee == a * Z + mz ? dz[ee] : dzs;
+        tt += LamF[MO][i * X + a] * dzs;
+      }
+    }
+    zl[e] = tt;
+  }
+  __syncthreads();
+  if (tid < RM * U) {  // dc/du rows of the iterate through generate_z'(u)
+    double G[Z * Z];
+    M::gz_jac(q, G);
+    const int i = tid / U, d = tid - i * U;
+    double tt = 0.0;
+    if (d < Z) {
+      for (int mz = 0; mz < Z; ++mz) {
+        double gs = 0.0;
+#pragma unroll
+        for (int ee = 0; ee < Z * Z; ++ee) gs = ee == mz * Z + d ? G[ee] : gs;
+        tt += zl[i * Z + mz] * gs;
+      }
+    } else {
+      tt = i < bd.ny ? sigma_at(sy, q) * q[sy.U + sy.NV + bd.obs0 + i] : 0.0;
+    }
+    JuS[tid] = tt;
+  }
+  __syncthreads();
+  // (f)
+  if (tid < 64) newton_factor16<M, RM, true, true>(sy, sl, w, prev, qsel, c, 0, tid < 16, Dl, JuS);
 }
 
 template <class M, int RM, int NW>
@@ -68,6 +218,10 @@ __global__ void __launch_bounds__(64 * NW)
   double* out = w.cpad + (size_t)c * sy.Kmax * RM;
   const int ncol = sy.T * sy.S + sy.V0 + (sy.noisy ? sy.T : 0);
   const KUpdatePB<RM, X, V, 0, 1> upd{sy, sl, w, prev, qsel, 0, CheckArgs{}};
+#ifdef CHMC_RETRACT_PROF
+  long long t0_ = wall_clock64();
+  if (tid == 0) atomicAdd(w.nfallback + 53, 1);
+#endif
   for (int it = 0;; ++it) {
     // ---- constraint values and trajectory of the iterate: first iteration from the state's own trajectory, later ones
     // from the previous iterate's (this buffer).  The sweeps go on until every junction has settled; after 64 NW sweeps
@@ -77,18 +231,27 @@ __global__ void __launch_bounds__(64 * NW)
       double Ul[X];
       int s0;
       bool have;
-      (void)fwd_par_sweeps<M, RM, NW>(sy, w, bd, q, xobs, traj, guess, out, 64 * NW + 2, it == 0 ? 2 : 1, Ul, s0, have);
+      (void)fwd_par_sweeps<M, RM, NW, 8>(sy, w, bd, q, xobs, traj, guess, out, 64 * NW + 2, it == 0 ? 2 : 1, Ul, s0, have);
       if (tid == 0)
         for (int i = bd.nrows; i < RM; ++i) out[i] = 0.0;  // padded constraint slots
     }
     wg_phase_sync();
+    CHMC_RPROF(48);
     // ---- interval sums against the previous point's compact rows
     for (int m = wv; m < bd.nobs; m += NW) newton_ivl_body<M, false>(sy, sl, w, prev, qsel, c, 0, m, bd);
     wg_phase_sync();
+    CHMC_RPROF(49);
     // ---- frames, Gram block, LU, core system, multipliers, mu_F; the u-part of the update, |c|_inf, |delta u|_inf
-    if (wv == 0) newton_comb_body<M, RM, false, true>(sy, sl, w, prev, qsel, c, 0, bd);
+    newton_comb_wg<M, RM, NW>(sy, sl, w, prev, qsel, c, bd);
     wg_phase_sync();
+    CHMC_RPROF(50);
     // ---- q_v -= mu_F[m] . PB[s] (and the v_0 / observation-noise columns), max |delta q|
+    // (Measured and rejected: two consecutive steps per work item (KUpdatePB<.., 2>): 19.6 -> 30.6 us per iteration; the loads of
+    // three steps issued before the first store: 42.5 us -- every variant that holds more than one step's 15 doubles per thread
+    // spills in this kernel, whose 256 registers are set by the scan and the factorisation.)
+    double err0 = 0.0;
+    unsigned long long nb0 = 0ULL;
+    if (tid == 0) err0 = w.err[c], nb0 = w.ndq[c];  // (left by the combine step; in flight under the update pass)
     unsigned long long r = 0ULL;
     for (int idx = tid; idx < ncol; idx += 64 * NW) {
       const unsigned long long v = upd(c, idx);
@@ -103,13 +266,13 @@ __global__ void __launch_bounds__(64 * NW)
     wg_phase_sync();
     // ---- the loop condition (:1119-1127) after this iteration, status mapping of the host wrapper (:1462-1476)
     if (tid == 0) {
-      unsigned long long nb = w.ndq[c];  // (the u-part, left by the combine step)
+      unsigned long long nb = nb0;  // (the u-part, left by the combine step)
 #pragma unroll
       for (int k = 0; k < NW; ++k) nb = sMax[k] > nb ? sMax[k] : nb;
       w.ndq[c] = nb;
       const int i = it + 1;
       w.iters[c] = i;
-      const double err = w.err[c], ndq = bitsd(nb);
+      const double err = err0, ndq = bitsd(nb);
       const bool diverged = (err > dtol) || (err != err);
       const bool converged = (err < ctol) && (ndq < ptol);
       const bool stop = i >= max_iters || diverged || converged;
@@ -122,6 +285,10 @@ __global__ void __launch_bounds__(64 * NW)
       sGo = stop ? 0 : 1;
     }
     wg_phase_sync();
+    CHMC_RPROF(51);
+#ifdef CHMC_RETRACT_PROF
+    if (tid == 0) atomicAdd(w.nfallback + 52, 1);
+#endif
     if (!sGo) break;  // (sGo is rewritten by the next iteration's check, four barriers on)
   }
 }

@@ -19,10 +19,10 @@ per doubling); the host draws the keyed uniforms and loops.
 
 All random choices come from `TreeUniforms`, keyed by (seed, transition, purpose, depth, leaf) and the global chain
 index, so they do not depend on how chains are sharded or on the order in which an implementation asks for them.  The
-chains' arithmetic is sharding-independent bit for bit as long as every shard runs the same forward-scan kernel: the library
-picks the time-parallel scan for few long blocks (chains x blocks per GPU <= 1024 with blocks of >= 1024 steps: the SIR
-single-block layout, or fewer than 52 FitzHugh-Nagumo chains per GPU), and that scan reproduces the sequential recursion
-to 1e-13 relative, not bitwise (csrc/chmc_wave.h k_fwd_par); CHMC_PAR_SCAN=0 / 1 fixes the choice.
+chains' arithmetic is sharding-independent bit for bit as well: the library chooses its kernels (time-parallel or
+sequential forward scan, interval-parallel or stored-rows 16-row sweeps, the per-chain retraction kernel) from the layout
+alone -- blocks per chain, block length, rows -- never from the number of chains in the context (csrc/chmc_api.inc
+few_long_blocks; GPU test test_results_do_not_depend_on_the_shard_size).
 """
 import numpy as np
 
