@@ -57,10 +57,7 @@ def parse():
     ap.add_argument("--burn-step-size", type=float, default=None)
     ap.add_argument("--lockstep", action="store_true",
                     help="one chmc_leapfrog_step call per step with the trajectory bookkeeping on the host instead of one "
-                         "chmc_leapfrog_steps call per trajectory (same batched steps underneath unless --engine async)")
-    ap.add_argument("--engine", default="lockstep", choices=["lockstep", "async"],
-                    help="implementation behind chmc_leapfrog_steps: lock-step batched steps (default) or the asynchronous "
-                         "per-chain-phase engine (sets CHMC_ASYNC=1)")
+                         "chmc_leapfrog_steps call per trajectory (same batched steps underneath)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="record no HIP events in the timed region")
     ap.add_argument("--profile-stride", type=int, default=1,
@@ -252,8 +249,6 @@ def _class_model_operator(nnz, Q, jac, gram_ns, gram_sym, f, n_s):
 
 def main():
     a = parse()
-    if a.engine == "async":
-        os.environ["CHMC_ASYNC"] = "1"
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         spawn_ranks(a)
     from manifold_mcmc_for_diffusions_amd import distributed as D
@@ -510,7 +505,7 @@ def main():
                 "workload": workload, "chains_per_gpu": B, "global_chains": world * B, "dim_q": ctx.Q,
                 "step_size": step_size, "traj_len": a.traj_len,
                 "stepping": ("chmc_leapfrog_step per step, host bookkeeping" if a.lockstep else
-                             "chmc_leapfrog_steps per trajectory, " + ("asynchronous per-chain phases" if os.environ.get("CHMC_ASYNC") == "1" else "lock-step batched steps")),
+                             "chmc_leapfrog_steps per trajectory (batched steps)"),
                 "chain_steps_attempted": total_steps, "chain_steps_nominal": world * B * a.steps,
                 "parallelism": f"chains x{world} (no data-path collective, 1 gather)",
                 "ranks_joined": int(agg[3]), "per_rank_ms": None if per_rank is None else [round(float(x), 2) for x in per_rank[:, 0]],

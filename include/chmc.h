@@ -205,8 +205,7 @@ int chmc_switch_partition(chmc_ctx* ctx);
  *   CHMC_HALVES=2           two overlapped half-batches per step
  *   read at every call:
  *   CHMC_NO_FWD_SCAN=1      generic functor instead of the hand-scheduled forward scan
- *   CHMC_RETRACT_KERNEL=0   one 16-row block per chain: lock-step Newton rounds instead of the per-chain retraction kernel
- *   CHMC_ASYNC=1            asynchronous per-chain-phase engine behind chmc_leapfrog_steps */
+ *   CHMC_RETRACT_KERNEL=0   one 16-row block per chain: lock-step Newton rounds instead of the per-chain retraction kernel */
 int chmc_constr(chmc_ctx* ctx, double* c);                                  /* :473-519, :1151-1155  [B][C] */
 /* :521-624, :1157-1161.  dc_du [B][C][U]; dc_dv [B][RM][NV] row-slot layout (slot i = row i of the block that
  * owns the column); dc/dn is sigma on observation rows (:601-608). */
@@ -273,14 +272,11 @@ int chmc_leapfrog_step(chmc_ctx* ctx, const double* dt, const int* active, int n
  * steps.  Outputs [B]: n_done (successful steps), status (0: all steps done; 1 / 2 / 3: the failing step's code; -1:
  * inactive), iters_fwd / iters_bwd (Newton iterations summed over the chain's steps, the failing one included), rev_err
  * (reverse-check distance of the last step that reached the check).
- * Two implementations of these semantics, same per-chain arithmetic (same kernels), tested bitwise equal:
- *  - lock-step (default): one batched chmc_leapfrog_step per step over the chains still running;
- *  - CHMC_ASYNC=1 (environment, read per call; needs n_inner_step == 1 and momenta known to be in the cotangent space):
- *    the asynchronous engine -- every chain moves through the phases of its steps (half-kick + flow, forward retraction,
- *    state evaluation, reverse retraction, check + half-kick) at its own pace, as the reference's sequential per-chain
- *    loops do (lax.while_loop :1119-1131 iterates as long as THAT chain needs); the batch only shares kernel launches
- *    and the state evaluations run on a second stream beside the retractions.  Measured slower than lock-step at the
- *    BASELINE shapes so far, hence not the default. */
+ * Implemented as one batched chmc_leapfrog_step per step over the chains still running (tests/test_trajectories.py: bitwise
+ * the host loop).  For layouts with one 16-row block per chain every retraction inside those steps already runs per chain,
+ * in the chain's own workgroup, for as many Newton iterations as THAT chain needs (k_retract_chain; lax.while_loop
+ * :1119-1131).  (Round 3's asynchronous per-chain-phase engine behind this entry point lost to the batched steps at every
+ * BASELINE shape and was removed in round 4.) */
 int chmc_leapfrog_steps(chmc_ctx* ctx, const double* dt, const int* active, const int* n_steps, int n_steps_all,
                         int n_inner_step, int newton, double constraint_tol, double position_tol, double divergence_tol,
                         int max_iters, double reverse_check_tol, int* n_done, int* status, int* iters_fwd, int* iters_bwd,

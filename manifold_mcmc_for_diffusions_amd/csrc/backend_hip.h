@@ -147,52 +147,6 @@ static void stagger_record() {
   note(hipEventRecord(g_stag_ev[h][g_stag_n[h] % kStagRing], g_stream));
   g_stag_n[h]++;
 }
-// ---- asynchronous trajectory engine (chmc_leapfrog_steps): (i) batches of state evaluations run on the auxiliary stream
-// behind everything the main stream has queued so far (aux_begin / aux_end, numbered by `slot`); the host asks with
-// aux_done() whether a batch has finished and only then makes the main stream depend on it (aux_join), so the main
-// stream never waits for a batch that is still running; (ii) small vectors of counts read back asynchronously.
-static const int kAuxSlots = 8;
-static thread_local hipEvent_t g_aux_fork[kAuxSlots], g_aux_done_ev[kAuxSlots];
-static thread_local bool g_aux_init = false;
-static thread_local hipStream_t g_aux_saved = nullptr;
-static void aux_init() {
-  if (g_aux_init) return;
-  for (int i = 0; i < kAuxSlots; ++i) {
-    note(hipEventCreateWithFlags(&g_aux_fork[i], hipEventDisableTiming));
-    note(hipEventCreateWithFlags(&g_aux_done_ev[i], hipEventDisableTiming));
-  }
-  g_aux_init = true;
-}
-static void aux_begin(int slot) {
-  aux_init();
-  note(hipEventRecord(g_aux_fork[slot], g_stream));
-  note(hipStreamWaitEvent(g_streams[2], g_aux_fork[slot], 0));
-  g_aux_saved = g_stream;
-  g_stream = g_streams[2];
-}
-static void aux_end(int slot) {
-  note(hipEventRecord(g_aux_done_ev[slot], g_stream));
-  g_stream = g_aux_saved;
-}
-static bool aux_done(int slot) { return hipEventQuery(g_aux_done_ev[slot]) == hipSuccess; }
-static void aux_join(int slot) { note(hipStreamWaitEvent(g_stream, g_aux_done_ev[slot], 0)); }
-static void aux_wait_host(int slot) { note(hipEventSynchronize(g_aux_done_ev[slot])); }
-static const int kPollvInts = 16;
-static thread_local int* g_pollv_host = nullptr;  // pinned, 4 slots of kPollvInts
-static thread_local hipEvent_t g_pollv_ev[4];
-static void pollv_begin(int slot, const int* d, int n) {
-  if (!g_pollv_host) {
-    note(hipHostMalloc((void**)&g_pollv_host, 4 * kPollvInts * sizeof(int), hipHostMallocDefault));
-    for (int i = 0; i < 4; ++i) note(hipEventCreateWithFlags(&g_pollv_ev[i], hipEventDisableTiming));
-  }
-  note(hipMemcpyAsync(g_pollv_host + slot * kPollvInts, d, n * sizeof(int), hipMemcpyDeviceToHost, g_stream));
-  note(hipEventRecord(g_pollv_ev[slot], g_stream));
-}
-static const int* pollv_end(int slot) {
-  note(hipEventSynchronize(g_pollv_ev[slot]));
-  return g_pollv_host + slot * kPollvInts;
-}
-static bool pollv_ready(int slot) { return hipEventQuery(g_pollv_ev[slot]) == hipSuccess; }
 static int dev_sync() {
   note(hipStreamSynchronize(g_stream));
   if (g_first_err != hipSuccess) {

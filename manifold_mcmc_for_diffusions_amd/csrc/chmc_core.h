@@ -139,7 +139,6 @@ struct Work {
   int* iters;       // [B]
   int* nw;          // [B] Newton loop: 0 finished, 1 iterating, 2 the time-parallel forward scan of the current iterate has
                     //     not settled yet: the chain sits this round out and its scan goes on in the next (k_fwd_par, K = 1)
-  int* nw2;         // asynchronous engine (use_nw == 3 in the forward scans): the reverse-retraction mask next to the
                     //     forward-retraction mask in `nw`; one merged scan serves both groups, each chain with its own
                     //     (slot, iterate) selection.  Null outside the engine.
   int* ok;          // [B] chain still good in this step
@@ -162,23 +161,10 @@ CHMC_HD inline T_* pick(T_* const (&a)[2], int s) {
   return s ? a[1] : a[0];
 }
 
-// Newton-phase kernels: is chain c part of the launch, and with which (prev, qsel)?  Outside the asynchronous engine
-// (work.nw2 == nullptr): the chains with work.nw == 1 and the launch's own arguments.  In the engine's merged launches
-// (work.nw2 != nullptr) both retraction directions share a launch: reverse-retraction chains (work.nw2 == 1: the previous
-// point is the proposal slot, the iterate work.qb: prev 1, qsel 1) and forward-retraction chains (work.nw == 1: prev 0,
-// qsel 0: the previous point is the state slot, the iterate the proposal slot's q).
+// Newton-phase kernels: is chain c part of the launch?  (prev / qsel are the launch's own arguments; the by-reference
+// parameters remain from round 3's asynchronous engine, whose merged launches picked them per chain.)
 CHMC_HD inline bool newton_select(const Work& w, int c, int& prev, int& qsel) {
-  if (w.nw2) {
-    if (w.nw2[c] == 1) {
-      prev = 1, qsel = 1;
-      return true;
-    }
-    if (w.nw[c] == 1) {
-      prev = 0, qsel = 0;
-      return true;
-    }
-    return false;
-  }
+  (void)prev, (void)qsel;
   return w.nw[c] == 1;
 }
 
@@ -628,11 +614,7 @@ struct KFwd {
   CHMC_HD void operator()(int tid) const {
     CHMC_CB_DECODE
     int which = this->which, qsel = this->qsel;
-    if (use_nw == 3) {  // asynchronous engine: forward-retraction chains (nw) and reverse-retraction chains (nw2)
-      int prev = 0;
-      if (!newton_select(w, c, prev, qsel)) return;
-      which = prev ^ 1;
-    } else if (use_nw ? w.nw[c] != 1 : !w.ok[c]) return;
+    if (use_nw ? w.nw[c] != 1 : !w.ok[c]) return;
     const int s = sl.cur[c] ^ which;
     const double* q = (qsel ? w.qb : pick(sl.q, s)) + (size_t)c * sy.Q;
     ChainConsts<M> cc;
@@ -1477,7 +1459,7 @@ struct KUpdate {
   }
   CHMC_HD unsigned long long operator()(int c, int idx) const {
     int which = this->which, qsel = this->qsel;
-    if (TGT == 0) newton_select(w, c, which, qsel);  // (merged launch of the asynchronous engine: the chain's own direction)
+    if (TGT == 0) newton_select(w, c, which, qsel);  // 
     const int s = sl.cur[c] ^ which;
     const int col = idx * VEC;
     const size_t qi = (size_t)c * sy.Q + sy.U + col;
@@ -1672,7 +1654,7 @@ struct KUpdatePB {  // NS: consecutive steps per work item (2 when S is even: bo
   CHMC_HD unsigned long long* red(int c) const { return TGT == 0 ? &w.ndq[c] : nullptr; }
   CHMC_HD unsigned long long operator()(int c, int idx) const {
     int which = this->which, qsel = this->qsel;
-    if (TGT == 0) newton_select(w, c, which, qsel);  // (merged launch of the asynchronous engine: the chain's own direction)
+    if (TGT == 0) newton_select(w, c, which, qsel);  // 
     const int s = sl.cur[c] ^ which;
     const size_t off = (size_t)c * sy.Q + sy.U;
     double* tgt = (TGT == 0 ? (qsel ? w.qb : pick(sl.q, s ^ 1))
@@ -2239,166 +2221,6 @@ struct KCommitInner {
       ncommit[c] += 1;
       w.rev[c] = 0ULL;  // the reported reverse-check distance is that of the last inner step
     }
-  }
-};
-// ------------------------------------------------------------------------------------------
-// Asynchronous trajectory engine (chmc_leapfrog_steps, chmc_api.inc): every chain walks through the phases of its own
-// leapfrog steps -- START (first half-kick + h2 flow), forward retraction (Newton iterations), state evaluation at the
-// new point + momentum projection + reverse flow, reverse retraction, FINISH (reversibility check, second half-kick,
-// commit) -- at its own pace: a chain whose retraction needs more iterations than its neighbours' does not hold them up,
-// and a chain whose trajectory has ended (all steps done, or a failed step) simply drops out.  The existing kernels are
-// reused unchanged through VIEWS: a copy of `Work` whose `nw` / `ok` pointer is one of the phase masks below, so that a
-// launch processes exactly the chains that are in the phase the launch belongs to.  Only the forward scan is shared
-// between the two retraction directions (use_nw == 3, Work::nw2).  Phase changes happen on the device in the functors
-// below; the host only decides which groups of kernels a round needs, from counts it reads back one round late.
-struct AsyncState {
-  int* mS;       // [B] START: the chain begins a leapfrog step in this round                (view: Work::ok)
-  int* mF;       // [B] forward retraction iterating: 0 / 1 / 2 (2: time-parallel scan not settled yet) (view: Work::nw)
-  int* mR;       // [B] reverse retraction iterating                                        (view: Work::nw, Work::nw2)
-  int* mM;       // [B] chains of the state-evaluation batch in flight                      (view: Work::ok)
-  int* mFin;     // [B] reverse retraction converged: reversibility check, half-kick, commit (view: Work::ok)
-  int* pend;     // [B] > 0: round in which the forward retraction converged; waiting for a state-evaluation batch
-  int* mid_gen;  // [B] > 0: generation of the state-evaluation batch that finished the chain; waiting for adoption
-  int* left;     // [B] leapfrog steps left in the chain's trajectory
-  int* ndone;    // [B] leapfrog steps completed
-  int* itf;      // [B] Newton iterations of the forward / reverse retractions, summed over the trajectory
-  int* itb;
-  unsigned long long* rev_last;  // [B] reverse-check distance of the chain's last checked step (bit pattern)
-  int* counts;   // [2][16] chains per phase (KAsyncCount), double-buffered by round parity
-  int* minconv;  // [4] fewest (0, 1) / most (2, 3) iterations a forward / reverse retraction has needed to converge (host heuristic:
-                 //     when a batch of state evaluations / a FINISH group can first be due after chains entered a phase)
-};
-struct KAsyncInit {  // after KBegin (work.ok = active, status 0 / -1, step sizes)
-  AsyncState as;
-  Work w;
-  const int* nsteps;  // per chain, or null: nsteps_all for every chain
-  int nsteps_all;
-  CHMC_HD void operator()(int c) const {
-    int n = w.ok[c] ? (nsteps ? nsteps[c] : nsteps_all) : 0;
-    if (n < 0) n = 0;
-    as.left[c] = n, as.ndone[c] = 0, as.itf[c] = 0, as.itb[c] = 0, as.rev_last[c] = 0ULL;
-    as.mS[c] = n > 0, as.mF[c] = 0, as.mR[c] = 0, as.mM[c] = 0, as.mFin[c] = 0, as.pend[c] = 0, as.mid_gen[c] = 0;
-  }
-};
-struct KAsyncNewtonBegin {  // KNewtonBegin for the chains entering a retraction
-  CHMC_HD static void run(const Work& w, int c) {
-    w.iters[c] = 0;
-    w.err[c] = -1.0;
-    w.ndq[c] = 0x7ff0000000000000ULL;  // +inf
-    w.nstat[c] = 0;
-  }
-};
-struct KAsyncStart {  // after KKickFlowPg on the START view: the chain's forward retraction begins
-  AsyncState as;
-  Work w;
-  CHMC_HD void operator()(int c) const {
-    if (!as.mS[c]) return;
-    as.mS[c] = 0, as.mF[c] = 1;
-    w.rev[c] = 0ULL;
-    KAsyncNewtonBegin::run(w, c);
-  }
-};
-// KCheck per phase: the lax.while_loop condition (:1119-1127) and status mapping (:1462-1476) for the chains of the view's
-// retraction (work.nw = mF or mR), plus the phase change of a chain whose retraction has ended
-struct KAsyncCheck {
-  AsyncState as;
-  Work w;  // (no view: the functor looks at both retraction masks)
-  double ctol, ptol, dtol;
-  int max_iters, round;
-  CHMC_HD void operator()(int c) const {
-    // dir 0: forward retraction (converged -> state evaluation), 1: reverse retraction (converged -> finish);
-    // mask 0: not in this phase; 2: its time-parallel scan has not settled (no iteration this round)
-    const int dir = as.mR[c] == 1 ? 1 : (as.mF[c] == 1 ? 0 : -1);
-    if (dir < 0) return;
-    const int i = ++w.iters[c];
-    const double err = w.err[c], ndq = bitsd(w.ndq[c]);
-    const bool diverged = (err > dtol) || (err != err);
-    const bool converged = (err < ctol) && (ndq < ptol);
-    if (!(i >= max_iters || diverged || converged)) return;
-    (dir ? as.mR : as.mF)[c] = 0;
-    const int st = converged ? 0 : (diverged ? 2 : 1);
-    w.nstat[c] = st;
-    (dir ? as.itb : as.itf)[c] += i;
-    if (st) {
-      w.status[c] = st;  // ConvergenceError: the step fails, the chain keeps its state and its trajectory ends
-      as.left[c] = 0;
-    } else if (dir == 0) {
-      as.pend[c] = round;
-      atomic_min_i32(as.minconv, i), atomic_max_i32(as.minconv + 2, i);
-    } else {
-      as.mFin[c] = 1;
-      atomic_min_i32(as.minconv + 1, i), atomic_max_i32(as.minconv + 3, i);
-    }
-  }
-};
-struct KAsyncRevCheck {  // after KRevDiff on the FINISH view
-  AsyncState as;
-  Work w;
-  double tol;
-  CHMC_HD void operator()(int c) const {
-    if (!as.mFin[c]) return;
-    as.rev_last[c] = w.rev[c];
-    if (!(bitsd(w.rev[c]) <= tol)) {  // NonReversibleStepError
-      as.mFin[c] = 0;
-      w.status[c] = 3;
-      as.left[c] = 0;
-    }
-  }
-};
-struct KAsyncCommit {  // after KKickPg on the FINISH view: the proposal slot becomes the state slot; next step or done
-  AsyncState as;
-  Slots sl;
-  CHMC_HD void operator()(int c) const {
-    if (!as.mFin[c]) return;
-    as.mFin[c] = 0;
-    sl.cur[c] ^= 1;
-    as.ndone[c] += 1;
-    if (--as.left[c] > 0) as.mS[c] = 1;
-  }
-};
-struct KAsyncMidBegin {  // a state-evaluation batch takes the chains that became ready in rounds <= rmax
-  AsyncState as;
-  int rmax;
-  CHMC_HD void operator()(int c) const {
-    const int p = as.pend[c];
-    if (p > 0 && p <= rmax) as.pend[c] = 0, as.mM[c] = 1;
-  }
-};
-struct KAsyncMidEnd {
-  AsyncState as;
-  int gen;
-  CHMC_HD void operator()(int c) const {
-    if (as.mM[c]) as.mM[c] = 0, as.mid_gen[c] = gen;
-  }
-};
-struct KAsyncAdopt {  // the main stream takes over the chains of a finished batch: their reverse retraction begins
-  AsyncState as;
-  Work w;
-  int gen;
-  CHMC_HD void operator()(int c) const {
-    if (as.mid_gen[c] != gen) return;
-    as.mid_gen[c] = 0, as.mR[c] = 1;
-    KAsyncNewtonBegin::run(w, c);
-  }
-};
-struct KAsyncCount {  // counts of round `round` into buffer round & 1 (zeroed by the previous round's launch, which also
-  AsyncState as;      // read it back); [0] busy, [1] forward retraction, [2] reverse retraction, [3] waiting for a
-  int round;          // state-evaluation batch, [4] starting, [5] finishing, [6], [7] = minconv
-  CHMC_HD void operator()(int c) const {
-    int* cnt = as.counts + 16 * (round & 1);
-    if (c == 0) {
-      int* nxt = as.counts + 16 * ((round + 1) & 1);
-      for (int i = 0; i < 16; ++i) nxt[i] = 0;
-      cnt[6] = as.minconv[0], cnt[7] = as.minconv[1], cnt[8] = as.minconv[2], cnt[9] = as.minconv[3];
-    }
-    const int f = as.mF[c] != 0, r = as.mR[c] != 0, wt = as.pend[c] != 0, st = as.mS[c] != 0, fn = as.mFin[c] != 0;
-    const int md = as.mM[c] != 0 || as.mid_gen[c] != 0;
-    if (f | r | wt | st | fn | md) atomic_add_i32(cnt, 1);
-    if (f) atomic_add_i32(cnt + 1, 1);
-    if (r) atomic_add_i32(cnt + 2, 1);
-    if (wt) atomic_add_i32(cnt + 3, 1);
-    if (st) atomic_add_i32(cnt + 4, 1);
-    if (fn) atomic_add_i32(cnt + 5, 1);
   }
 };
 struct KCopyPadMasked {  // dst[c][:] = src[c][:] for the chains of the view (block-padded [B][n] arrays)

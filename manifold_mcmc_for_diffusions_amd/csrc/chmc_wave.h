@@ -4573,16 +4573,9 @@ __global__ void __launch_bounds__(64) k_xobs_par(Sys sy, Slots sl, double* xobs_
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Is chain c part of this scan launch, and which iterate does it integrate?  use_nw 0: chains with work.ok; 1: chains of
-// the Newton loop (work.nw == 1); 3: the asynchronous engine's merged scan -- forward-retraction chains (work.nw: iterate
-// = the proposal slot's q) and reverse-retraction chains (work.nw2: iterate = work.qb) in one launch.
+// Is chain c part of this scan launch?  use_nw 0: chains with work.ok; 1: chains of the Newton loop (work.nw == 1).
 __device__ inline bool scan_select(const Work& w, int c, int use_nw, int& which, int& qsel) {
-  if (use_nw == 3) {  // (same selection as newton_select, chmc_core.h; which = prev ^ 1)
-    const bool rev = w.nw2[c] == 1;
-    if (!rev && w.nw[c] != 1) return false;
-    which = rev ? 0 : 1, qsel = rev ? 1 : 0;
-    return true;
-  }
+  (void)which, (void)qsel;
   return use_nw ? w.nw[c] == 1 : w.ok[c] != 0;
 }
 template <class M, int RM, bool STORE>
@@ -5206,7 +5199,7 @@ __global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, in
   // chain whose retraction is diverging (healthy blocks settle in 2-9 sweeps): it is handed to the sequential
   // recursion, which costs the same 0.9 ms as the remaining sweeps would
   constexpr int X = M::X, V = M::V;
-  // Inside a Newton loop (lock-step: use_nw == 1; asynchronous engine: use_nw == 3) with ONE block per chain a scan that has
+  // Inside a Newton loop (use_nw == 1) with ONE block per chain a scan that has
   // not settled after CHMC_PAR_MAXS_ROUND sweeps is neither integrated sequentially nor handed to another stream: its
   // junction states are kept in the trajectory buffer, the chain's mask becomes 2 -- the round's other kernels and the
   // convergence check skip it, it takes no iteration -- and the next round's launch goes on sweeping from there.  A launch
@@ -5216,26 +5209,15 @@ __global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, in
   // 22.7 k against 26.3 k steps/s.
   // (With several blocks per chain the chain's mask would be shared by wavefronts that settle and wavefronts that do not:
   // those layouts keep 12 sweeps and the sequential recursion inside the launch, as outside a loop.)
-  const bool async = use_nw == 3;
-  const bool apend = (async || use_nw == 1) && sy.K == 1;
+  const bool apend = use_nw == 1 && sy.K == 1;
   const int MAXS = apend ? CHMC_PAR_MAXS_ROUND : 12;
   const int gl = W > 1 ? (int)threadIdx.x : (int)(threadIdx.x & 63);  // segment of the block
   const int wid = blockIdx.x;
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];
   const int c = cbi / sy.K, b = cbi - c * sy.K;
-  int* amask = nullptr;  // async: the mask entry of this chain's retraction
-  if (async) {
-    const int f = w.nw[c], r = w.nw2[c];
-    if (r == 1 || r == 2) {
-      amask = w.nw2 + c, which = 0, qsel = 1;
-    } else if (f == 1 || f == 2) {
-      amask = w.nw + c, which = 1, qsel = 0;
-    } else {
-      return;
-    }
-    gsel = (*amask == 2 || w.iters[c] > 0) ? 1 : 2;  // own previous sweeps / previous iterate; first iteration: the state's trajectory
-  } else if (use_nw) {
+  int* amask = nullptr;  // the chain's mask entry when an unsettled scan is carried over to the next round
+  if (use_nw) {
     const int f = w.nw[c];
     if (f != 1 && !(apend && f == 2)) return;
     if (apend) {

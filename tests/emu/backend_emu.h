@@ -21,17 +21,6 @@ static void stagger_wait() {}
 static void stagger_record() {}
 static void poll_begin(int slot, const int* d) { g_poll_val[slot] = *d; }
 static int poll_end(int slot) { return g_poll_val[slot]; }
-// asynchronous engine: the auxiliary stream's batches run inline, a batch is finished as soon as it has been enqueued
-static const int kAuxSlots = 8;
-static void aux_begin(int) {}
-static void aux_end(int) {}
-static bool aux_done(int) { return true; }
-static void aux_join(int) {}
-static void aux_wait_host(int) {}
-static int g_pollv_val[4][16];
-static void pollv_begin(int slot, const int* d, int n) { memcpy(g_pollv_val[slot], d, n * sizeof(int)); }
-static const int* pollv_end(int slot) { return g_pollv_val[slot]; }
-static bool pollv_ready(int) { return true; }
 template <class F>
 static void launch(F f, long n, int cls = 0) {
   (void)cls;

@@ -1,8 +1,8 @@
-"""chmc_leapfrog_steps (whole trajectories, every chain at its own pace) against chmc_leapfrog_step applied repeatedly
-with the trajectory semantics spelled out on the host (a chain stops at its first failed step) and against the C oracle.
-CPU: the TEST-ONLY emulation build (sequencing logic of the engine: phase masks, hand-overs between the main loop and
-the state-evaluation batches, termination); `-m gpu`: the HIP library (tests/test_hip_parity.py holds the full-size
-cases)."""
+"""chmc_leapfrog_steps (whole trajectories in one library call: the loop an integration transition runs around
+integrator.step, scripts/utils.py:284-301) against chmc_leapfrog_step applied repeatedly with the trajectory semantics
+spelled out on the host (a chain stops at its first failed step) and against the C oracle.
+CPU: the TEST-ONLY emulation build (the call's bookkeeping); `-m gpu`: the HIP library (tests/test_hip_parity.py holds
+the full-size single-step cases)."""
 import numpy as np
 import pytest
 from helpers import make_case, make_ctx
@@ -11,12 +11,6 @@ from test_emu_logic import emu_lib  # noqa: F401
 import os
 
 SOLVER = dict(max_iters=12)
-
-
-@pytest.fixture(autouse=True)
-def _engine_on(monkeypatch):
-    """chmc_leapfrog_steps runs the asynchronous engine only with CHMC_ASYNC=1 (read at every call)."""
-    monkeypatch.setenv("CHMC_ASYNC", "1")
 
 
 def lockstep_trajectories(ctx, dts, n_steps, active=None, **kw):
@@ -45,7 +39,7 @@ def lockstep_trajectories(ctx, dts, n_steps, active=None, **kw):
 
 
 def run_both(case, dts, n_steps, active=None, part=0, newton=True, seed=5, **kw):
-    """Engine and lock-step path from identical states; returns (engine result, lock-step result, states)."""
+    """The library call and the host loop from identical states; returns (library result, host-loop result) with states."""
     B = case["B"]
     rng = np.random.default_rng(seed)
     qq = np.repeat(case["q"][:1], B, 0)
@@ -89,7 +83,7 @@ CASES = [
 @pytest.mark.parametrize("newton", [True, False])
 def test_trajectories_equal_repeated_steps(emu_lib, model, T, S, R, noisy, gaussian, newton):  # noqa: F811
     """Mixed step sizes (chains need different numbers of Newton iterations), per-chain trajectory lengths, inactive
-    chains and a chain whose first step fails: bitwise the results of the lock-step path."""
+    chains and a chain whose first step fails: bitwise the results of the host loop."""
     B = 7
     case = make_case(model, T, S, R, noisy, B=B, seed=21, gaussian=gaussian)
     dts = np.array([0.05, -0.05, 0.1, 0.02, 5.0, -0.08, 0.03])
@@ -104,17 +98,11 @@ def test_trajectories_equal_repeated_steps(emu_lib, model, T, S, R, noisy, gauss
         assert (r["n_done"][[0, 1, 2, 6]] <= n_steps[[0, 1, 2, 6]]).all() and r["n_done"].sum() >= 6
 
 
-def test_default_and_unprojected_momenta_take_the_lockstep_path(emu_lib, monkeypatch):  # noqa: F811
-    """Without CHMC_ASYNC=1 (the default) and with momenta not known to be tangent: same semantics through the lock-step
-    batched steps; the engine counts its rounds, the lock-step path its Newton loops' rounds."""
+def test_unprojected_momenta(emu_lib):  # noqa: F811
+    """Momenta set through set_state (not projected): the first step must take the reference's full path for its first
+    half-kick (no tangent-momentum shortcut), in the library call as in the host loop."""
     case = make_case("fhn", 6, 4, 2, True, B=4, seed=22)
     dts = np.array([0.05, -0.05, 0.1, 0.02])
-    a, b = run_both(case, dts, 3, **SOLVER)
-    monkeypatch.delenv("CHMC_ASYNC")
-    a2, b2 = run_both(case, dts, 3, **SOLVER)
-    assert_same(a2, b2), assert_same(a, a2)
-    monkeypatch.setenv("CHMC_ASYNC", "1")
-    # momenta set through set_state (not projected): the library must not use the tangent-momentum shortcut
     B = 4
     ctx = make_ctx(case)
     rng = np.random.default_rng(3)
@@ -130,7 +118,6 @@ def test_default_and_unprojected_momenta_take_the_lockstep_path(emu_lib, monkeyp
     for k in ("n_done", "status", "iters_fwd", "iters_bwd"):
         np.testing.assert_array_equal(r1[k], r2[k])
     assert np.array_equal(s1[0], s2[0]) and np.array_equal(s1[1], s2[1])
-    assert_same(a, b)
 
 
 def test_trajectories_against_the_oracle(emu_lib):  # noqa: F811
@@ -176,8 +163,8 @@ GPU_CASES = [
 @pytest.mark.gpu
 @pytest.mark.parametrize("model,T,S,R,noisy,gaussian,newton", GPU_CASES)
 def test_trajectories_equal_repeated_steps_hip(model, T, S, R, noisy, gaussian, newton):
-    """The engine on the MI355X against the lock-step path of the same library: 37 chains (partial wavefronts), mixed
-    step sizes, per-chain trajectory lengths, inactive and failing chains -- bitwise (same kernels through mask views)."""
+    """On the MI355X: 37 chains (partial wavefronts), mixed step sizes, per-chain trajectory lengths, inactive and failing
+    chains -- bitwise the host loop's results."""
     from manifold_mcmc_for_diffusions_amd import _lib
     assert _lib.lib().chmc_backend() == b"hip:gfx950"
     B = 37
@@ -196,8 +183,8 @@ def test_trajectories_equal_repeated_steps_hip(model, T, S, R, noisy, gaussian, 
 
 @pytest.mark.gpu
 def test_trajectories_full_size_distinct_chains_hip():
-    """BASELINE.json configs[1] at full size, 72 distinct chains, trajectories of 3 steps: the engine against the lock-step
-    path (bitwise) and its first step against the C oracle chain by chain."""
+    """BASELINE.json configs[1] at full size, 72 distinct chains, trajectories of 3 steps: the library call against the host
+    loop (bitwise) and its first step against the C oracle chain by chain."""
     from oracle import c_oracle
     from test_hip_parity import _distinct_on_manifold_chains
     B = 72
@@ -243,10 +230,9 @@ def test_trajectories_full_size_distinct_chains_hip():
 
 @pytest.mark.gpu
 def test_trajectories_sir_single_block_time_parallel_scan_hip():
-    """BASELINE.json configs[3]'s shape (one 14-row block of 2 800 steps: 16-row kernels, time-parallel forward scan whose
-    unsettled sweeps carry over to the next round): 72 distinct chains, trajectories of 4 steps against the lock-step
-    path -- statuses and step counts equal, iteration counts equal except on a tolerance edge, positions to 1e-9 (the
-    time-parallel scan reproduces the sequential recursion to 1e-13, not bitwise)."""
+    """BASELINE.json configs[3]'s shape (one 14-row block of 2 800 steps: per-chain retraction kernel, time-parallel scans,
+    interval-parallel 16-row state evaluation): 72 distinct chains, trajectories of 4 steps against the host loop --
+    statuses, step counts and iteration counts equal, positions to 1e-9."""
     from test_hip_parity import _distinct_on_manifold_chains
     B = 72
     case = _distinct_on_manifold_chains("sir", 14, 200, 14, B, seed=73, obs_interval=0.25)
