@@ -7,7 +7,7 @@
 //
 // Data layout in HBM (B chains, all fp64, chain-major so a chain's state is contiguous):
 //   q, p, grad   [B][Q]            q = [u(U) | v_0(V0) | v_seq(T*S*V) | n(T)]  (:476-484)
-//   traj         [B][T*S+Kmax][X]  per block nsteps+1 states (x_s before step s)
+//   traj         [B][T*S+16 Kmax][X]  per block nsteps+1 states (x_s before step s), rows line-aligned (CHMC_TPAD)
 //   Jv           [B][RM][NV]       "row-slot" Jacobian: slot i holds row i of the block that
 //                                  owns the column, so J^T lambda / J w / Gram builds are
 //                                  unit-stride streams over the v-part of q
@@ -35,6 +35,12 @@ namespace chmc {
 #define CHMC_FWD_DEPTH 4  // tiles of noise increments in flight in the forward scans
 #endif
 #define CHMC_Q_PAD 256 // doubles of slack after every [B][Q] position buffer (see fwd_block)
+// Trajectory layout [B][T S + CHMC_TPAD Kmax][X]: block b of a chain stores its nsteps + 1 states from entry step0 +
+// CHMC_TPAD b on.  The padding keeps every block's row on a 128-byte line whenever its first step is (16 states are 256 /
+// 384 bytes for X = 2 / 3): with the rows one state apart (round 1-3) seven of eight blocks started 16 bytes into a line,
+// every 128-byte tile the forward scan's helper wavefront stores straddled two lines, and the counters showed 165 MB
+// written for a 129 MB trajectory.
+#define CHMC_TPAD 16
 
 struct BlockDesc {
   int obs0, nobs, first, last;
@@ -620,7 +626,7 @@ struct KFwd {
     ChainConsts<M> cc;
     cc.init(q, sy.dl);
     // store_traj: 0 none, 1 into the slot, 2 into the Newton-iterate work trajectory
-    double* traj = store_traj ? (store_traj == 2 ? w.trajw : pick(sl.traj, s)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * M::X
+    double* traj = store_traj ? (store_traj == 2 ? w.trajw : pick(sl.traj, s)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * M::X
                               : nullptr;
     double cp[RM];
     fwd_block<M, RM>(sy, bd, cc, q, sy.xobs + (size_t)c * sy.T * M::X, traj, cp);
@@ -749,7 +755,7 @@ struct KStateBlk {
     const double* q = pick(sl.q, s) + (size_t)c * sy.Q;
     ChainConsts<M> cc;
     cc.init(q, sy.dl);
-    double* traj = pick(sl.traj, s) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * M::X;
+    double* traj = pick(sl.traj, s) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * M::X;
     double cp[RM];
     fwd_block<M, RM>(sy, bd, cc, q, sy.xobs + (size_t)c * sy.T * M::X, traj, cp);
     double* cout_ = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
@@ -852,7 +858,7 @@ struct KGldBlk {
     const int S = sy.S, L = bd.nsteps, NV = sy.NV;
     const size_t cb = (size_t)c * sy.Kmax + b;
     const double* q = pick(sl.q, s) + (size_t)c * sy.Q;
-    const double* traj = pick(sl.traj, s) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+    const double* traj = pick(sl.traj, s) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
     const double* Jv = pick(sl.Jv, s) + (size_t)c * RM * NV;
     const double* v = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
     const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
@@ -1186,7 +1192,7 @@ struct KNewtonBlk {
     const double* q = (qsel ? w.qb : pick(sl.q, sp ^ 1)) + (size_t)c * sy.Q;
     ChainConsts<M> cc;
     cc.init(q, sy.dl);
-    double* traj = w.trajw + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * M::X;
+    double* traj = w.trajw + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * M::X;
     double cp[RM];
     fwd_block<M, RM>(sy, bd, cc, q, sy.xobs + (size_t)c * sy.T * M::X, traj, cp);
     const size_t cb = (size_t)c * sy.Kmax + b;

@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(256) k_rev_wave(Sys sy, Slots sl, Work w, int 
   const size_t cb = (size_t)c * sy.Kmax + b;
   const int S = sy.S, NV = sy.NV;
   const double* q = (MODE == 1 ? (qsel ? w.qb : pick(sl.q, sl_ ^ 1)) : pick(sl.q, sl_)) + (size_t)c * sy.Q;
-  const double* traj = (MODE == 1 ? w.trajw : pick(sl.traj, sl_)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* traj = (MODE == 1 ? w.trajw : pick(sl.traj, sl_)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
   const double* Jr = pick(sl.Jv, sl_) + (size_t)c * RM * NV;  // MODE 1: read; MODE 0: written through Jo
   double* Jo = (MODE == 1 ? w.JvW : pick(sl.Jv, sl_)) + (size_t)c * RM * NV;
   double* PBo = nullptr;  // compact rows of the evaluated state (MODE 0 with frames): Slots::PB / Slots::LF
@@ -740,7 +740,7 @@ __global__ void __launch_bounds__(64, (PBJ && M::X * M::V <= 4) ? CHMC_LEAN_WAVE
   const size_t cb = (size_t)c * sy.Kmax + b;
   const int S = sy.S, NV = sy.NV;
   const double* q = (STATE ? pick(sl.q, sl_) : (qsel ? w.qb : pick(sl.q, sl_ ^ 1))) + (size_t)c * sy.Q;
-  const double* traj = (STATE ? pick(sl.traj, sl_) : w.trajw) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* traj = (STATE ? pick(sl.traj, sl_) : w.trajw) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
   const double* Jr = pick(sl.Jv, sl_) + (size_t)c * RM * NV;
   const double* PBr = PBJ ? pick(sl.PB, sl_) + ((size_t)c * sy.T * S + bd.step0) * (X * V) : nullptr;
   const double* LFr = PBJ ? pick(sl.LF, sl_) + cb * sy.NOBS * RM * X : nullptr;
@@ -1299,7 +1299,7 @@ __device__ __forceinline__ void newton_ivl_body(const Sys& sy, const Slots& sl, 
   const size_t cb = (size_t)c * sy.Kmax + b;
   const int S = sy.S;
   const double* q = (STATE ? pick(sl.q, sl_) : (qsel ? w.qb : pick(sl.q, sl_ ^ 1))) + (size_t)c * sy.Q;
-  const double* traj = (STATE ? pick(sl.traj, sl_) : w.trajw) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X + (size_t)m * S * X;
+  const double* traj = (STATE ? pick(sl.traj, sl_) : w.trajw) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X + (size_t)m * S * X;
   double* PBr = pick(sl.PB, sl_) + ((size_t)c * sy.T * S + bd.step0 + (size_t)m * S) * (X * V);  // (STATE: written)
   const double* vbase = q + sy.U + sy.V0 + ((size_t)bd.step0 + (size_t)m * S) * V;
   ChainConsts<M> cc;
@@ -1446,7 +1446,7 @@ __device__ __forceinline__ void newton_comb_body(const Sys& sy, const Slots& sl,
   const size_t cb = (size_t)c * sy.Kmax + b;
   const int S = sy.S, NV = sy.NV;
   const double* q = (STATE ? pick(sl.q, sl_) : (qsel ? w.qb : pick(sl.q, sl_ ^ 1))) + (size_t)c * sy.Q;
-  const double* traj = (STATE ? pick(sl.traj, sl_) : w.trajw) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* traj = (STATE ? pick(sl.traj, sl_) : w.trajw) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
   double* Jr = pick(sl.Jv, sl_) + (size_t)c * RM * NV;  // (STATE: the v_0 columns are written)
   double* LFr = pick(sl.LF, sl_) + cb * sy.NOBS * RM * X;  // (STATE: written)
   auto lds_sync = [&]() {
@@ -1609,7 +1609,7 @@ __global__ void __launch_bounds__(64) k_rev_wave_ldsrows(Sys sy, Slots sl, Work 
   const size_t cb = (size_t)c * sy.Kmax + b;
   const int S = sy.S, NV = sy.NV;
   const double* q = (MODE == 1 ? (qsel ? w.qb : pick(sl.q, sl_ ^ 1)) : pick(sl.q, sl_)) + (size_t)c * sy.Q;
-  const double* traj = (MODE == 1 ? w.trajw : pick(sl.traj, sl_)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* traj = (MODE == 1 ? w.trajw : pick(sl.traj, sl_)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
   double* Jo = (MODE == 1 ? w.JvW : pick(sl.Jv, sl_)) + (size_t)c * RM * NV;
   ChainConsts<M> cc;
   cc.init(q, sy.dl);
@@ -2315,7 +2315,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_wave(Sys sy, Slots sl, Work w, 
   const int S = sy.S, NV = sy.NV;
   const size_t TS = (size_t)sy.T * S;
   const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
-  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
   const double* Jv = pick(sl.Jv, s_) + (size_t)c * RM * NV;
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
   const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
@@ -2562,7 +2562,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_qx(Sys sy, Slots sl, Work w, in
   const int S = sy.S, NV = sy.NV;
   const size_t TS = (size_t)sy.T * S;
   const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
-  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
   const double* Jv = pick(sl.Jv, s_) + (size_t)c * RM * NV;
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
   double* Xd = w.Xd + (size_t)c * RM * X * TS + bd.step0;
@@ -2772,7 +2772,7 @@ __global__ void __launch_bounds__(PBJ && CHMC_GLD_BWD_WAVES > 1 ? 64 : 256, PBJ 
   const int S = sy.S, NV = sy.NV;
   const size_t TS = (size_t)sy.T * S;
   const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
-  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
   const double* Jv = pick(sl.Jv, s_) + (size_t)c * RM * NV;
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
   const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
@@ -3049,7 +3049,7 @@ __global__ void __launch_bounds__(64, CHMC_GLD_LEAN_WAVES) k_gld_bwd_lean(Sys sy
   const int S = sy.S;
   const size_t TS = (size_t)sy.T * S;
   const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
-  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
   const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
   const double* Xq = w.Xd + (size_t)c * RM * X * TS + bd.step0;  // Qx, component-major: [X X][T S]
@@ -3410,7 +3410,7 @@ __global__ void __launch_bounds__(256) k_gld_fwd_ivl(Sys sy, Slots sl, Work w, i
   const int S = sy.S;
   const size_t TS = (size_t)sy.T * S;
   const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
-  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
   double* Xd = w.Xd + (size_t)c * RM * X * TS + bd.step0;
   const double* PBr = pick(sl.PB, s_) + ((size_t)c * TS + bd.step0) * (X * V);
@@ -3526,7 +3526,7 @@ __global__ void __launch_bounds__(256) k_gld_bwd_ivl(Sys sy, Slots sl, Work w, i
   const int S = sy.S;
   const size_t TS = (size_t)sy.T * S;
   const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
-  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
   const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
   const double* Xq = w.Xd + (size_t)c * RM * X * TS + bd.step0;  // Qx, component-major: [X X][T S]
@@ -3825,7 +3825,7 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave_ldsrows(Sys sy, Slots sl, 
   const int S = sy.S, NV = sy.NV;
   const size_t TS = (size_t)sy.T * S;
   const double* q = pick(sl.q, s_) + (size_t)c * sy.Q;
-  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const double* traj = pick(sl.traj, s_) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
   const double* Jv = pick(sl.Jv, s_) + (size_t)c * RM * NV;
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
   const size_t colb = (size_t)sy.V0 + (size_t)bd.step0 * V;
@@ -4468,9 +4468,9 @@ __global__ void __launch_bounds__(64) k_xobs_par(Sys sy, Slots sl, double* xobs_
   const bool have = s0 < L;
   double Ul[X];
   {
-    const int b0 = have ? sy.obs2blk[s0 / S] : 0;  // step s of block b sits at trajectory entry s + b
+    const int b0 = have ? sy.obs2blk[s0 / S] : 0;  // step s of block b sits at trajectory entry s + CHMC_TPAD b
 #pragma unroll
-    for (int a = 0; a < X; ++a) Ul[a] = lane == 0 ? x0[a] : (have ? trj[(size_t)(s0 + b0) * X + a] : 0.0);
+    for (int a = 0; a < X; ++a) Ul[a] = lane == 0 ? x0[a] : (have ? trj[(size_t)(s0 + CHMC_TPAD * b0) * X + a] : 0.0);
   }
   bool converged = false;
   for (int sweep = 0; sweep < MAXS && !converged; ++sweep) {
@@ -4578,8 +4578,14 @@ __device__ inline bool scan_select(const Work& w, int c, int use_nw, int& which,
   (void)which, (void)qsel;
   return use_nw ? w.nw[c] == 1 : w.ok[c] != 0;
 }
+// Helper wavefronts per workgroup that issue the trajectory stores (they share a tile's rows: helper h takes the 1 KB store
+// instructions i = h mod CHMC_SCAN_HELPERS).  Measured with the line-aligned trajectory rows (round 4, configs[1]): one helper
+// 113.0 us per launch, two 112.0 us -- the helper is not short of store slots (vmcnt), one stays the default.
+#ifndef CHMC_SCAN_HELPERS
+#define CHMC_SCAN_HELPERS 1
+#endif
 template <class M, int RM, bool STORE>
-__global__ void __launch_bounds__(STORE ? 128 : 64)
+__global__ void __launch_bounds__(STORE ? 64 * (1 + CHMC_SCAN_HELPERS) : 64)
     k_fwd_scan(Sys sy, Slots sl, Work w, int which, int qsel, int use_nw, int store_traj) {
   constexpr int X = M::X, V = M::V, PF = 8;
   constexpr int NLD = PF * V / 2;        // 16-byte loads per lane and tile
@@ -4602,7 +4608,9 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
   __shared__ __attribute__((aligned(16))) double tile[STORE ? 2 : 1][STORE ? NB * 64 * RSD : 2];
   __shared__ double obsv[64 * (2 * RM + 1)];
   const int lane = threadIdx.x & 63;
-  const bool helper = STORE && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) != 0;
+  const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const bool helper = STORE && wave_id != 0;
+  const int hid = wave_id - 1;  // which helper
   const int n = sy.B * sy.K, S = sy.S;
   const int tid0 = blockIdx.x * 64;
 
@@ -4641,7 +4649,7 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
         if (scan_select(w, c, use_nw, wh_, qs_)) {
           const BlockDesc bd = sy.blk[b];
           const int s = sl.cur[c] ^ wh_;
-          rp[i] = (store_traj == 2 ? w.trajw : pick(sl.traj, s)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X + 2 * ch;
+          rp[i] = (store_traj == 2 ? w.trajw : pick(sl.traj, s)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X + 2 * ch;
           rL[i] = bd.nsteps;
         }
       }
@@ -4658,10 +4666,11 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
         if (st < maxL) {
           d2_t tt[NST];
 #pragma unroll
-          for (int i = 0; i < NST; ++i) tt[i] = *reinterpret_cast<const d2_t*>(&tile[buf][sl_ * 64 * RSD + lo_[i]]);
+          for (int i = 0; i < NST; ++i)
+            if (i % CHMC_SCAN_HELPERS == hid) tt[i] = *reinterpret_cast<const d2_t*>(&tile[buf][sl_ * 64 * RSD + lo_[i]]);
 #pragma unroll
           for (int i = 0; i < NST; ++i)
-            if (st < rL[i]) vm_store16_nt(rp[i] + (size_t)st * X, tt[i]);
+            if (i % CHMC_SCAN_HELPERS == hid && st < rL[i]) vm_store16_nt(rp[i] + (size_t)st * X, tt[i]);
         }
       }
       buf ^= 1;
@@ -4762,7 +4771,7 @@ __global__ void __launch_bounds__(STORE ? 128 : 64)
   for (int d = 0; d < DEPTH; ++d) vm_wait<0>(ring[d]);  // nothing may land in a register after this point
   if (!act) return;
   if (STORE) {
-    double* trow = (store_traj == 2 ? w.trajw : pick(sl.traj, s)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+    double* trow = (store_traj == 2 ? w.trajw : pick(sl.traj, s)) + (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
 #pragma unroll
     for (int a = 0; a < X; ++a) trow[(size_t)L * X + a] = x[a];
   }
@@ -5233,7 +5242,7 @@ __global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, in
   const int S = sy.S, L = bd.nsteps;
   const double* q = (qsel ? w.qb : pick(sl.q, s_)) + (size_t)c * sy.Q;
   const double* xobs = sy.xobs + (size_t)c * sy.T * X;
-  const size_t toff = (size_t)c * sy.TRJ + (size_t)(bd.step0 + b) * X;
+  const size_t toff = (size_t)c * sy.TRJ + (size_t)(bd.step0 + CHMC_TPAD * b) * X;
   double* traj = (store_traj == 2 ? w.trajw : pick(sl.traj, s_)) + toff;
   const double* guess = gsel == 2 ? pick(sl.traj, sl.cur[c]) + toff : gsel == 3 ? w.trajw + toff : traj;
   double* out = w.cpad + ((size_t)c * sy.Kmax + b) * RM;
