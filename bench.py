@@ -69,7 +69,63 @@ def parse():
                          "operator analogue of the reference's JAX path, eager and unjitted) at BASELINE.json configs[0]'s "
                          "shape (S = 50) on one core: about two minutes")
     ap.add_argument("--data-steps-per-obs", type=int, default=10000, help="fine grid of the simulated FHN data")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run (configs[1], one GPU) only: skip the short legs of the other single-GPU BASELINE shapes "
+                         "that follow the headline's timed region (config.other_configs)")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="the timed region is repeated this many times AFTER the official one (same K steps each) for the "
+                         "run-to-run spread (config.value_repeats); `value` is always the first, official region")
     return ap.parse_args()
+
+
+def config_key(config, S, B):
+    """Key of a workload in profiles/traffic.json: the bench configuration plus the shape when it is not the default one."""
+    k = config
+    if S != (200 if config == "sir" else 400):
+        k += f"_s{S}"
+    if B != 256:
+        k += f"_b{B}"
+    return k
+
+
+OTHER_CONFIGS = [  # the other single-GPU BASELINE.json shapes, run as short child legs after the headline (name, bench arguments)
+    ("configs[2] fhn_noiseless S=400 x 256", ["--config", "fhn_noiseless"]),
+    ("configs[3] shard: sir S=200 x 256", ["--config", "sir"]),
+    ("configs[4] shard: fhn_noisy S=800 x 512", ["--config", "fhn_noisy", "--num-steps-per-obs", "800", "--chains-per-gpu", "512"]),
+]
+
+
+def run_other_configs(a):
+    """Short legs of the other single-GPU BASELINE shapes, each in a fresh child process (its own context; this process
+    keeps its own): 4 warm-up + 16 timed steps, no CPU baseline.  Returns {name: summary or {"error": ...}}."""
+    import subprocess
+    out = {}
+    for name, extra in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--steps", "16",
+               "--warmup", "4", "--repeats", "0"] + extra
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not line:
+                out[name] = {"error": f"exit code {r.returncode}: {r.stderr.strip()[-300:]}"}
+                continue
+            d = json.loads(line[-1])
+            c, rf = d["config"], d["roofline"]
+            out[name] = {
+                "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                "workload": c["workload"], "newton_rounds_per_step": c["newton_rounds_per_step"],
+                "mean_newton_iters_fwd_plus_bwd": c["mean_newton_iters_fwd_plus_bwd"],
+                "step_success_rate": c["step_success_rate"], "launches_per_step": c["launches_per_step"],
+                "nominal_steps_per_s": c.get("nominal_steps_per_s"),
+                "roofline": {k: rf.get(k) for k in ("kernel", "bound", "frac", "achieved", "peak", "unit", "traffic",
+                                                    "avg_launch_ms", "traffic_source")},
+                "whole_step_hbm_frac": c.get("whole_step_hbm_frac"), "wall_s": round(time.perf_counter() - t0, 1),
+                "command": "python bench.py " + " ".join(cmd[2:]),
+            }
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": repr(e)[:300]}
+    return out
 
 
 def spawn_ranks(a):
@@ -381,6 +437,19 @@ def main():
     L.chmc_profile_get(ms.ctypes.data_as(_lib.dp), nl.ctypes.data_as(C.POINTER(C.c_longlong)))
     L.chmc_profile_enable(0)
     L.chmc_profile_stride(1)
+    counters_after = ctx.counters()["projection_iterations"]
+    # run-to-run spread: the same region again (K steps + gather, no HIP events), after the official one
+    rep_local = []
+    for _ in range(max(a.repeats, 0)):
+        st_r = []
+        D.barrier()
+        sync()
+        tr0 = time.perf_counter()
+        run_steps(a.steps, st_r)
+        gather_segment()
+        D.barrier()
+        sync()
+        rep_local.append((time.perf_counter() - tr0, float(sum(x["attempted"] for x in st_r))))
     t_max = D.max_over_ranks(elapsed)
     per_rank = D.gather_samples(np.array([[elapsed * 1e3]]), equal_shards=True)
 
@@ -390,6 +459,13 @@ def main():
     n_clean = float(sum(x["steps_clean"] for x in stats))
     k_mean = (sum(x["iters_ok"] for x in stats) / n_clean) if n_clean else float("nan")  # (steps of calls without a failure)
     agg = D.sum_over_ranks([n_ok, attempted, iters_all, 1.0])
+    repeats = None
+    if rep_local:
+        rt = [D.max_over_ranks(t) for t, _ in rep_local]
+        ra = [float(D.sum_over_ranks([n])[0]) for _, n in rep_local]
+        vals = [n / t for n, t in zip(ra, rt)]
+        repeats = {"values": [round(v, 1) for v in vals], "min": round(min(vals), 1), "max": round(max(vals), 1),
+                   "note": "the timed region repeated after the official one (same K steps, no HIP events)"}
     if rank == 0:
         # chain-steps actually attempted: a chain whose step fails ends its trajectory ("failed steps count
         # as work done and end that chain's trajectory"); with every step succeeding this is chains x steps
@@ -403,10 +479,15 @@ def main():
         if os.path.exists(tf) and not emu:
             try:
                 tj = json.load(open(tf))
-                if tj.get("_lib_sha256") == lib_sha256() and tj.get("_config", "fhn_noisy") == a.config:
-                    traffic_all, traffic_note = tj, f"profiles/traffic.json ({tj.get('_command', 'rocprofv3 --pmc passes')}), same library build"
+                key = config_key(a.config, S, B)
+                sect = tj.get("configs", {}).get(key)
+                if tj.get("_lib_sha256") != lib_sha256():
+                    traffic_note = "profiles/traffic.json is from another build of the library: not quoted"
+                elif wl.solver["newton"] is False or gaussian or sect is None:
+                    traffic_note = f"profiles/traffic.json holds no counters for this workload ({key}): not quoted"
                 else:
-                    traffic_note = "profiles/traffic.json is from another build or configuration: not quoted"
+                    traffic_all = sect
+                    traffic_note = f"profiles/traffic.json [{key}] ({sect.get('_command', 'rocprofv3 --pmc passes')}), same library build"
             except Exception as e:  # noqa: BLE001
                 traffic_note = f"profiles/traffic.json unreadable ({e})"
         # chains one launch processes: the Newton-loop kernels are masked per chain, so the later iterations of a solve
@@ -422,7 +503,7 @@ def main():
         elif name in ("update", "constr", "solve_chain", "sym_blk") and nl[dom]:
             # one masked launch per Newton / quasi-Newton iteration (the chains still iterating) plus the launches
             # that run over every chain (state evaluation, momentum projections)
-            full = max(launches_all - float(ctx.counters()["projection_iterations"] - iters_before), 0.0)
+            full = max(launches_all - float(counters_after - iters_before), 0.0)
             chains_per_launch = (pairs + B * full) / launches_all
         else:
             chains_per_launch = float(B)
@@ -496,7 +577,7 @@ def main():
         if traffic_all:
             whole_bytes = float(sum(traffic_all[k] * table[k]["launches_per_step"] for k in table if traffic_all.get(k)))
             whole_frac = whole_bytes / (t_max / a.steps) / 1e9 / HBM_PEAK_GBS
-        rounds_per_step = (ctx.counters()["projection_iterations"] - iters_before) / max(a.steps, 1)
+        rounds_per_step = (counters_after - iters_before) / max(a.steps, 1)
         out = {
             "metric": METRIC, "value": value, "unit": "steps/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": t_max / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -507,6 +588,10 @@ def main():
                 "stepping": ("chmc_leapfrog_step per step, host bookkeeping" if a.lockstep else
                              "chmc_leapfrog_steps per trajectory (batched steps)"),
                 "chain_steps_attempted": total_steps, "chain_steps_nominal": world * B * a.steps,
+                # (`value` counts chain-steps ATTEMPTED -- a chain whose step fails ends its trajectory, SURVEY 8d;
+                # rounds 1-2 quoted chains x steps / time, which is this figure)
+                "nominal_steps_per_s": world * B * a.steps / t_max,
+                "value_repeats": repeats,
                 "parallelism": f"chains x{world} (no data-path collective, 1 gather)",
                 "ranks_joined": int(agg[3]), "per_rank_ms": None if per_rank is None else [round(float(x), 2) for x in per_rank[:, 0]],
                 "mean_newton_iters_fwd_plus_bwd": k_mean, "step_success_rate": float(agg[0] / agg[1]),
@@ -532,6 +617,9 @@ def main():
             out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
             if a.cpu_autodiff_baseline:
                 out["cpu_baseline"]["autodiff_restatement_S50"] = cpu_autodiff_baseline()
+        if world == 1 and a.config == "fhn_noisy" and not a.no_other_configs and not emu and wl.solver["newton"] \
+                and not gaussian and B == 256 and S == 400:
+            out["config"]["other_configs"] = run_other_configs(a)
         print(json.dumps(_finite(out)), flush=True)
     D.barrier()
     ctx.close()

@@ -10,7 +10,9 @@ each kernel class follows); the factor used per class is recorded in the output 
 WRITE_SIZE is taken as is.
 The output records the SHA-256 of the library that was profiled (`_lib_sha256`), the bench configuration and the
 command, and bench.py quotes `roofline.traffic` from it only when they match the build it is timing.
-usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [config] [command]"""
+usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> [workload key] [command]
+(the output file is keyed by workload: bench.py config_key -- fhn_noisy, fhn_noiseless, sir, fhn_noisy_s800_b512 -- and is
+started afresh when the library build changes)"""
 import hashlib
 import json
 import os
@@ -24,7 +26,8 @@ CLASS_OF = [  # substring of the kernel name -> profiling class of include/chmc.
     ("k_newton_lean<chmc::FhnModel, 7, true, true>", "state_blk"), ("k_newton_lean<chmc::FhnModel, 6, true, true>", "state_blk"),
     ("k_newton_lean<chmc::FhnModel, 8, true, true>", "state_blk"), ("k_newton_lean<chmc::SirModel, 8, true, true>", "state_blk"),
     ("k_newton_lean<chmc::FhnNbModel, 6, true, true>", "state_blk"), ("k_newton_lean<chmc::FhnNbModel, 8, true, true>", "state_blk"),
-    ("k_newton_lean", "newton_blk"), ("k_newton_ivl", "newton_blk"), ("k_newton_comb", "newton_blk"),
+    ("k_newton_ivl<chmc::SirModel, true>", "state_blk"), ("k_newton_comb<chmc::SirModel, 16, true", "state_blk"),
+    ("k_newton_lean", "newton_blk"), ("k_newton_ivl", "newton_blk"), ("k_newton_comb", "newton_blk"), ("k_retract_chain", "newton_blk"),
     ("k_newton_factor_wave", "sym_blk"), ("k_gram_rows", "newton_blk"), ("KUpdatePB", "update"), ("KMuF", "solve_chain"),
     ("k_jw_pb", "jacob_vec"), ("KRowsFromPB", "state_blk"),
     ("k_rev_wave_ldsrows<chmc::SirModel, 16, 1", "newton_blk"), ("k_rev_wave_ldsrows<chmc::SirVsModel, 16, 1", "newton_blk"),
@@ -71,24 +74,32 @@ def main():
     f = per_class(sys.argv[1], "FETCH_SIZE")
     w = per_class(sys.argv[2], "WRITE_SIZE")
     fac, fac_src = fetch_factors()
-    res = {"_method": "bytes per launch = (factor * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the launches of the "
-                      "class; factor = calibrated bytes-per-FETCH_SIZE of the class's access pattern (`_fetch_factor`); "
-                      "two separate rocprofv3 --pmc passes of `bench.py --steps 4 --warmup 2`",
-           "_fetch_factor": {}, "_fetch_factor_source": fac_src}
-    res["_lib_sha256"] = hashlib.sha256(open(SO, "rb").read()).hexdigest()
-    res["_config"] = sys.argv[4] if len(sys.argv) > 4 else "fhn_noisy"
-    res["_command"] = sys.argv[5] if len(sys.argv) > 5 else "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 2"
+    sha = hashlib.sha256(open(SO, "rb").read()).hexdigest()
+    key = sys.argv[4] if len(sys.argv) > 4 else "fhn_noisy"
+    # one file for every profiled workload of ONE library build: {"_lib_sha256", "configs": {key: {class: bytes per launch}}}
+    res = {}
+    if os.path.exists(sys.argv[3]):
+        try:
+            res = json.load(open(sys.argv[3]))
+        except ValueError:
+            res = {}
+    if res.get("_lib_sha256") != sha or "configs" not in res:
+        res = {"_method": "bytes per launch = (factor * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the launches of the "
+                          "class; factor = calibrated bytes-per-FETCH_SIZE of the class's access pattern (`_fetch_factor`); "
+                          "two separate rocprofv3 --pmc passes of `bench.py --steps 4 --warmup 2` per workload",
+               "_fetch_factor_source": fac_src, "_lib_sha256": sha, "configs": {}}
+    sect = {"_fetch_factor": {}}
+    sect["_command"] = sys.argv[5] if len(sys.argv) > 5 else "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 2"
     for cls in sorted(set(f) | set(w)):
         fs, fn = f.get(cls, (0.0, 1))
         ws, wn = w.get(cls, (0.0, 1))
         k = fac.get(cls, 2.0)
-        res["_fetch_factor"][cls] = k
-        res[cls] = (k * fs / max(fn, 1) + ws / max(wn, 1)) * 1024.0
-        res[cls + "_detail"] = {"fetch_KB_raw": fs / max(fn, 1), "write_KB": ws / max(wn, 1), "launches": fn}
+        sect["_fetch_factor"][cls] = k
+        sect[cls] = (k * fs / max(fn, 1) + ws / max(wn, 1)) * 1024.0
+        sect[cls + "_detail"] = {"fetch_KB_raw": fs / max(fn, 1), "write_KB": ws / max(wn, 1), "launches": fn}
+    res["configs"][key] = sect
     json.dump(res, open(sys.argv[3], "w"), indent=1)
-    # launches per class in the profiled command (for the whole-step sum of bench.py)
-    res["_launches"] = {cls: int(max(f.get(cls, (0, 0))[1], w.get(cls, (0, 0))[1])) for cls in set(f) | set(w)}
-    print(json.dumps({k: v for k, v in res.items() if not k.endswith("_detail") and not k.startswith("_")}, indent=1))
+    print(key, json.dumps({k: v for k, v in sect.items() if not k.endswith("_detail") and not k.startswith("_")}, indent=1))
 
 
 if __name__ == "__main__":
