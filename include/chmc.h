@@ -311,7 +311,8 @@ int chmc_get_counters(const chmc_ctx* ctx, long long* out8);
  *   out80[64]      launches of the fp64-MFMA Gram kernel (v_mfma_f64_16x16x4_f64; 16-row blocks, CHMC_GRAM_MFMA=1)
  *   out80[65]      launches of the vector-FMA Gram kernel over stored rows (16-row blocks)
  *   out80[66]      launches of the per-chain retraction kernel (k_retract_chain: one 16-row block per chain)
- *   out80[67 .. 79] reserved (0)
+ *   out80[67]      launches of the per-chain trajectory kernel (k_traj_chain: whole leapfrog steps of such a chain)
+ *   out80[68 .. 79] reserved (0)
  * Synchronises the context's stream. */
 int chmc_get_diagnostics(chmc_ctx* ctx, long long* out80);
 

@@ -404,7 +404,7 @@ class ChmcContext:
         check(self.L.chmc_get_diagnostics(self.h, out), "chmc_get_diagnostics")
         v = np.array(out[:], dtype=np.int64)
         return dict(par_scan=v[:64], gram_mfma_launches=int(v[64]), gram_valu_launches=int(v[65]),
-                    retract_kernel_launches=int(v[66]))
+                    retract_kernel_launches=int(v[66]), traj_kernel_launches=int(v[67]), extra=v[68:80])
 
     def counters(self):
         out = (C.c_longlong * 8)()

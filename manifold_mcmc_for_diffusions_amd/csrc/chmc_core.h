@@ -23,6 +23,9 @@
 #include <stdint.h>
 #include "chmc_model.h"
 
+// functors that the per-chain kernels (chmc_retract.h) call from inside their phase loops: a real call there makes the kernel
+// obey the function ABI, which cost the scan's sweep loop 180 spilled registers
+#define CHMC_FI __attribute__((always_inline))
 #if defined(__HIPCC__)
 #define CHMC_UNROLL _Pragma("unroll")
 #else
@@ -792,7 +795,7 @@ struct KStateChain {
   Slots sl;
   Work w;
   int which;
-  CHMC_HD void operator()(int c) const {
+  CHMC_FI CHMC_HD void operator()(int c) const {
     if (!w.ok[c]) return;
     constexpr int U = M::U;
     const int s = sl.cur[c] ^ which;
@@ -1159,7 +1162,7 @@ struct KGldChain {
   Slots sl;
   Work w;
   int which;
-  CHMC_HD void operator()(int c) const {
+  CHMC_FI CHMC_HD void operator()(int c) const {
     if (!w.ok[c]) return;
     constexpr int U = M::U;
     const int s = sl.cur[c] ^ which;
@@ -1271,7 +1274,7 @@ struct KStateFactor {  // Cholesky of D = Jv Jv^T + diag, D^-1 dc/du, C_b, log d
   Slots sl;
   Work w;
   int which;
-  CHMC_HD void operator()(int tid) const {
+  CHMC_FI CHMC_HD void operator()(int tid) const {
     CHMC_CB_DECODE
     if (!w.ok[c]) return;
     (void)bd;
@@ -1302,7 +1305,7 @@ struct KSymBlk {
   Slots sl;
   Work w;
   int which, use_nw;
-  CHMC_HD void operator()(int tid) const {
+  CHMC_FI CHMC_HD void operator()(int tid) const {
     CHMC_CB_DECODE
     int which = this->which, qsel_unused = 0;
     if (use_nw ? !newton_select(w, c, which, qsel_unused) : !w.ok[c]) return;
@@ -1594,7 +1597,7 @@ struct KMuF {
   Slots sl;
   Work w;
   int which;
-  CHMC_HD void operator()(int tid) const {
+  CHMC_FI CHMC_HD void operator()(int tid) const {
     const int a = tid % X;
     int r = tid / X;
     const int m = r % sy.NOBS;
@@ -1658,7 +1661,7 @@ struct KUpdatePB {  // NS: consecutive steps per work item (2 when S is even: bo
     return TGT == 0 ? newton_select(w, c, p_, q_) : w.ok[c] != 0;
   }
   CHMC_HD unsigned long long* red(int c) const { return TGT == 0 ? &w.ndq[c] : nullptr; }
-  CHMC_HD unsigned long long operator()(int c, int idx) const {
+  CHMC_FI CHMC_HD unsigned long long operator()(int c, int idx) const {
     int which = this->which, qsel = this->qsel;
     if (TGT == 0) newton_select(w, c, which, qsel);  // 
     const int s = sl.cur[c] ^ which;
@@ -2005,7 +2008,7 @@ struct KKickPg {
   int which, out_other;
   double hfrac;
   CHMC_HD bool active(int c) const { return w.ok[c] != 0; }
-  CHMC_HD void operator()(int c, int col) const {  // row launch: components col, col + 1 of chain c
+  CHMC_FI CHMC_HD void operator()(int c, int col) const {  // row launch: components col, col + 1 of chain c
     const int s = sl.cur[c] ^ which;
     const double h = hfrac * w.dt[c];
     const size_t i = (size_t)c * sy.Q + col;
@@ -2024,7 +2027,7 @@ struct KFlow {
   int from, dst, from_p_other;
   double sign;
   CHMC_HD bool active(int c) const { return w.ok[c] != 0; }
-  CHMC_HD void operator()(int c, int col) const {  // row launch: components col, col + 1 of chain c
+  CHMC_FI CHMC_HD void operator()(int c, int col) const {  // row launch: components col, col + 1 of chain c
     const int s = sl.cur[c] ^ from;
     const double dt = sign * w.dt[c];
     const size_t i = (size_t)c * sy.Q + col;
@@ -2065,7 +2068,7 @@ struct KMomFixInitPg {
   Work w;
   int which;
   CHMC_HD bool active(int c) const { return w.ok[c] != 0; }
-  CHMC_HD void operator()(int c, int col) const {  // row launch: components col, col + 1 of chain c
+  CHMC_FI CHMC_HD void operator()(int c, int col) const {  // row launch: components col, col + 1 of chain c
     const int s = sl.cur[c] ^ which;
     const size_t i = (size_t)c * sy.Q + col;
     const bool two = col + 1 < sy.Q, wide = two && !(sy.Q & 1);
@@ -2117,7 +2120,7 @@ struct KKickFlowPg {
   Work w;
   double hfrac;
   CHMC_HD bool active(int c) const { return w.ok[c] != 0; }
-  CHMC_HD void operator()(int c, int col) const {  // row launch: components col, col + 1 of chain c
+  CHMC_FI CHMC_HD void operator()(int c, int col) const {  // row launch: components col, col + 1 of chain c
     const int s = sl.cur[c];
     const double h = hfrac * w.dt[c];
     const size_t i = (size_t)c * sy.Q + col;
@@ -2158,7 +2161,7 @@ struct KRevDiff {
   Work w;
   CHMC_HD bool active(int c) const { return w.ok[c] != 0; }
   CHMC_HD unsigned long long* red(int c) const { return &w.rev[c]; }
-  CHMC_HD unsigned long long operator()(int c, int idx) const {
+  CHMC_FI CHMC_HD unsigned long long operator()(int c, int idx) const {
     const int col = 2 * idx;
     const size_t i = (size_t)c * sy.Q + col;
     const double* qs = pick(sl.q, sl.cur[c]);
@@ -2178,7 +2181,7 @@ struct KRevDiff {
 struct KRevCheck {
   Work w;
   double tol;
-  CHMC_HD void operator()(int c) const {
+  CHMC_FI CHMC_HD void operator()(int c) const {
     if (!w.ok[c]) return;
     const double r = bitsd(w.rev[c]);
     if (!(r <= tol)) w.ok[c] = 0, w.status[c] = 3;
@@ -2187,7 +2190,7 @@ struct KRevCheck {
 struct KCommit {  // accept: the proposal slot becomes the state slot
   Slots sl;
   Work w;
-  CHMC_HD void operator()(int c) const {
+  CHMC_FI CHMC_HD void operator()(int c) const {
     if (w.ok[c]) sl.cur[c] ^= 1;
   }
 };

@@ -48,6 +48,15 @@ namespace chmc {
   } while (0)
 #endif
 
+// The chain index as a value the optimiser cannot see through: every phase of the per-chain kernels derives its addresses
+// from its own opaque copy, so that loop-invariant code motion does not hoist the address arithmetic of ALL phases to the
+// top of the step / iteration loop, where it would stay live through every hot loop (measured: 177 scratch instructions
+// in the scan's sweep loop of the fused kernel against 19 with the copies).
+__device__ __forceinline__ int opaque_u(int v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+
 __device__ __forceinline__ void wg_phase_sync() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
@@ -186,14 +195,13 @@ __device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, c
   if (tid < 64) newton_factor16<M, RM, true, true>(sy, sl, w, prev, qsel, c, 0, tid < 16, Dl, JuS);
 }
 
+// The retraction of chain c by the calling workgroup (every thread calls it; returns with the chain's loop finished: status
+// in work.nstat / ok / status, counts in work.iters and *iters_dst, the last iterate's trajectory in work.trajw).
 template <class M, int RM, int NW>
-__global__ void __launch_bounds__(64 * NW)
-    k_retract_chain(Sys sy, Slots sl, Work w, int prev, int qsel, double ctol, double ptol, double dtol, int max_iters,
-                    int* iters_dst) {
+__device__ __forceinline__ void retract_chain_body(const Sys& sy, const Slots& sl, const Work& w, int c, int prev, int qsel,
+                                                   double ctol, double ptol, double dtol, int max_iters, int* iters_dst) {
   constexpr int X = M::X, V = M::V;
   static_assert(RM == 16, "one 16-row block per chain");
-  const int c = blockIdx.x;  // K == 1: the work order of the wave-per-block kernels is the identity
-  if (c >= sy.B) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   __shared__ unsigned long long sMax[NW];
   __shared__ int sGo;
@@ -210,14 +218,7 @@ __global__ void __launch_bounds__(64 * NW)
   if (!active || max_iters <= 0) return;  // (uniform over the workgroup)
   const BlockDesc bd = sy.blk[0];
   const int which = prev ^ 1;
-  const int s_ = sl.cur[c] ^ which;  // slot of the iterate (unless it is work.qb)
-  const double* q = (qsel ? w.qb : pick(sl.q, s_)) + (size_t)c * sy.Q;
-  const double* xobs = sy.xobs + (size_t)c * sy.T * X;
-  const size_t toff = (size_t)c * sy.TRJ + (size_t)bd.step0 * X;
-  double* traj = w.trajw + toff;
-  double* out = w.cpad + (size_t)c * sy.Kmax * RM;
   const int ncol = sy.T * sy.S + sy.V0 + (sy.noisy ? sy.T : 0);
-  const KUpdatePB<RM, X, V, 0, 1> upd{sy, sl, w, prev, qsel, 0, CheckArgs{}};
 #ifdef CHMC_RETRACT_PROF
   long long t0_ = wall_clock64();
   if (tid == 0) atomicAdd(w.nfallback + 53, 1);
@@ -227,22 +228,32 @@ __global__ void __launch_bounds__(64 * NW)
     // from the previous iterate's (this buffer).  The sweeps go on until every junction has settled; after 64 NW sweeps
     // the exact prefix has reached the end of the block whatever the guess.
     {
-      const double* guess = it == 0 ? pick(sl.traj, sl.cur[c]) + toff : traj;
+      const int ca = opaque_u(c);  // (every phase from its own copy of the chain index: see opaque_u)
+      const int s_ = sl.cur[ca] ^ which;  // slot of the iterate (unless it is work.qb)
+      const double* q = (qsel ? w.qb : pick(sl.q, s_)) + (size_t)ca * sy.Q;
+      const size_t toff = (size_t)ca * sy.TRJ + (size_t)bd.step0 * X;
+      double* traj = w.trajw + toff;
+      double* out = w.cpad + (size_t)ca * sy.Kmax * RM;
+      const double* guess = it == 0 ? pick(sl.traj, sl.cur[ca]) + toff : traj;
       double Ul[X];
       int s0;
       bool have;
-      (void)fwd_par_sweeps<M, RM, NW, 8>(sy, w, bd, q, xobs, traj, guess, out, 64 * NW + 2, it == 0 ? 2 : 1, Ul, s0, have);
+      (void)fwd_par_sweeps<M, RM, NW, 8>(sy, w, bd, q, sy.xobs + (size_t)ca * sy.T * X, traj, guess, out, 64 * NW + 2,
+                                         it == 0 ? 2 : 1, Ul, s0, have);
       if (tid == 0)
         for (int i = bd.nrows; i < RM; ++i) out[i] = 0.0;  // padded constraint slots
     }
     wg_phase_sync();
     CHMC_RPROF(48);
     // ---- interval sums against the previous point's compact rows
-    for (int m = wv; m < bd.nobs; m += NW) newton_ivl_body<M, false>(sy, sl, w, prev, qsel, c, 0, m, bd);
+    {
+      const int cb_ = opaque_u(c);
+      for (int m = wv; m < bd.nobs; m += NW) newton_ivl_body<M, false>(sy, sl, w, prev, qsel, cb_, 0, m, bd);
+    }
     wg_phase_sync();
     CHMC_RPROF(49);
     // ---- frames, Gram block, LU, core system, multipliers, mu_F; the u-part of the update, |c|_inf, |delta u|_inf
-    newton_comb_wg<M, RM, NW>(sy, sl, w, prev, qsel, c, bd);
+    newton_comb_wg<M, RM, NW>(sy, sl, w, prev, qsel, opaque_u(c), bd);
     wg_phase_sync();
     CHMC_RPROF(50);
     // ---- q_v -= mu_F[m] . PB[s] (and the v_0 / observation-noise columns), max |delta q|
@@ -251,11 +262,15 @@ __global__ void __launch_bounds__(64 * NW)
     // spills in this kernel, whose 256 registers are set by the scan and the factorisation.)
     double err0 = 0.0;
     unsigned long long nb0 = 0ULL;
-    if (tid == 0) err0 = w.err[c], nb0 = w.ndq[c];  // (left by the combine step; in flight under the update pass)
+    const int cu = opaque_u(c);
+    if (tid == 0) err0 = w.err[cu], nb0 = w.ndq[cu];  // (left by the combine step; in flight under the update pass)
     unsigned long long r = 0ULL;
-    for (int idx = tid; idx < ncol; idx += 64 * NW) {
-      const unsigned long long v = upd(c, idx);
-      r = v > r ? v : r;
+    {
+      const KUpdatePB<RM, X, V, 0, 1> upd{sy, sl, w, prev, qsel, 0, CheckArgs{}};
+      for (int idx = tid; idx < ncol; idx += 64 * NW) {
+        const unsigned long long v = upd(cu, idx);
+        r = v > r ? v : r;
+      }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -290,6 +305,228 @@ __global__ void __launch_bounds__(64 * NW)
     if (tid == 0) atomicAdd(w.nfallback + 52, 1);
 #endif
     if (!sGo) break;  // (sGo is rewritten by the next iteration's check, four barriers on)
+  }
+}
+template <class M, int RM, int NW>
+__global__ void __launch_bounds__(64 * NW)
+    k_retract_chain(Sys sy, Slots sl, Work w, int prev, int qsel, double ctol, double ptol, double dtol, int max_iters,
+                    int* iters_dst) {
+  const int c = blockIdx.x;  // K == 1: the work order of the wave-per-block kernels is the identity
+  if (c >= sy.B) return;
+  retract_chain_body<M, RM, NW>(sy, sl, w, c, prev, qsel, ctol, ptol, dtol, max_iters, iters_dst);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Whole constrained leapfrog steps of a chain -- a whole trajectory -- in one kernel, one workgroup per chain.
+//
+// With the retraction per chain (above) a step of the batch still waited twice for its slowest chain: a launch of
+// k_retract_chain lasts as long as the chain that needs the most Newton iterations (a diverging retraction runs 10 - 30
+// iterations before |c| passes the divergence tolerance; at 1 % failing chain-steps nearly every launch of 256 chains has
+// one: mean launch 1.9 ms for a mean chain time of 0.9 ms), and the 21 kernels of the state evaluation and momentum
+// projection between the two retractions are launch-latency work for 256 chains.  Nothing in a step crosses chains
+// (scripts/utils.py:351-363 runs the chains one after the other), so the workgroup that owns the chain walks the whole
+// step -- A(dt/2) + h2 flow | forward retraction | state evaluation (scan, interval sums, combine, Cholesky, chain core,
+// grad log det sweeps) | momentum correction + projection | reverse flow | reverse retraction | reversibility check |
+// A(dt/2) | commit (mici ConstrainedLeapfrogIntegrator.step) -- with workgroup barriers between the phases,
+// and goes on to the chain's next step: n_steps[c] steps per call (the loop of an integration transition around
+// integrator.step, scripts/utils.py:284-301), ended by the chain's first failed step.  A slow chain costs only itself.
+// Every phase is the device function of the corresponding kernel of the lock-step path (same arithmetic per chain);
+// phases hand over through the same global work arrays.
+template <class F>
+__device__ __forceinline__ void wg_rows(const F& f, int c, int ncol, int nt) {  // k_rows for one chain
+  if (!f.active(c)) return;
+  for (int col = 2 * (int)threadIdx.x; col < ncol; col += 2 * nt) f(c, col);
+}
+__device__ __forceinline__ void wave_sync() {  // the calling wavefront's own global / LDS accesses have completed
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <class M, int RM, int NW>
+__global__ void __launch_bounds__(64 * NW)
+    k_traj_chain(Sys sy, Slots sl, Work w, const int* n_steps, int n_steps_all, double ctol, double ptol, double dtol,
+                 int max_iters, double rev_tol, int* itf, int* itb, int* n_done) {
+  constexpr int X = M::X, V = M::V, NT = 64 * NW;
+  const int c = blockIdx.x;
+  if (c >= sy.B) return;
+  const int tid = threadIdx.x, wv = tid >> 6;
+  __shared__ int sOk;
+  __shared__ unsigned long long sRev[NW];
+  const BlockDesc bd = sy.blk[0];
+  const int nst = n_steps ? n_steps[c] : n_steps_all;
+  const int ncol = sy.T * sy.S + sy.V0 + (sy.noisy ? sy.T : 0);
+  const double kick = 0.5;
+  unsigned long long rev_last = 0ULL;
+  int done = 0;
+  auto chain_ok = [&]() {  // work.ok[c] as seen by every thread (written by thread 0 / lane 0 of the phases before)
+    wg_phase_sync();
+    if (tid == 0) sOk = w.ok[c];
+    wg_phase_sync();
+    return sOk != 0;
+  };
+  if (!chain_ok()) return;  // inactive chain (status -1 from KBegin)
+#ifdef CHMC_RETRACT_PROF
+  long long tq_ = wall_clock64();
+#define CHMC_TPROF(slot)                                      \
+  do {                                                        \
+    if (tid == 0) {                                           \
+      const long long t1_ = wall_clock64();                   \
+      atomicAdd(w.nfallback + 64 + (slot), (int)((t1_ - tq_) >> 4)); /* 160 ns units */ \
+      tq_ = t1_;                                              \
+    }                                                         \
+  } while (0)
+#else
+#define CHMC_TPROF(slot) \
+  do {                   \
+  } while (0)
+#endif
+  for (int step = 0; step < nst; ++step) {
+    if (tid == 0) w.rev[c] = 0ULL;
+    // ---- A(dt/2) for a tangent momentum (p - dt/2 pg) and the h2 flow into the proposal slot
+    wg_rows(KKickFlowPg{sy, sl, w, kick}, c, sy.Q, NT);
+    wg_phase_sync();
+    const int c1 = opaque_u(c);
+    CHMC_TPROF(0);
+    // ---- retraction onto the manifold
+    retract_chain_body<M, RM, NW>(sy, sl, w, c1, 0, 0, ctol, ptol, dtol, max_iters, itf);
+    if (!chain_ok()) break;
+    const int c2 = opaque_u(c);
+    CHMC_TPROF(1);
+    // ---- J, Gram factors, log det, grad log det at the new point (state_eval_core(1, true, 3), 16-row interval-parallel form)
+    {
+      const int s1 = sl.cur[c2] ^ 1;
+      const size_t toff = (size_t)c2 * sy.TRJ + (size_t)bd.step0 * X;
+      const double* q1 = pick(sl.q, s1) + (size_t)c2 * sy.Q;
+      double* traj1 = pick(sl.traj, s1) + toff;
+      double* out = w.cpad + (size_t)c2 * sy.Kmax * RM;
+      double Ul[X];
+      int s0;
+      bool have;
+      (void)fwd_par_sweeps<M, RM, NW, 8>(sy, w, bd, q1, sy.xobs + (size_t)c2 * sy.T * X, traj1, w.trajw + toff, out,
+                                         64 * NW + 2, 3, Ul, s0, have);
+      if (tid == 0)
+        for (int i = bd.nrows; i < RM; ++i) out[i] = 0.0;
+    }
+    wg_phase_sync();
+    const int c3 = opaque_u(c);
+    CHMC_TPROF(2);
+    for (int m = wv; m < bd.nobs; m += NW) newton_ivl_body<M, true>(sy, sl, w, 1, 0, c3, 0, m, bd);
+    wg_phase_sync();
+    const int c4 = opaque_u(c);
+    CHMC_TPROF(3);
+    if (wv == 0) {
+      newton_comb_body<M, RM, true, false>(sy, sl, w, 1, 0, c4, 0, bd);
+      wave_sync();
+      if (tid == 0) {
+        KStateFactor<M, RM>{sy, sl, w, 1}(c4);  // (K == 1: work item c4 K + 0)
+        KStateChain<M>{sy, sl, w, 1}(c4);
+      }
+      wave_sync();
+      gld_prep_body<M, RM>(sy, sl, w, 1, c4, 1);
+      wave_sync();
+      gld_ivl_prologue_body<M, RM>(sy, sl, w, 1, c4, 0);
+    }
+    wg_phase_sync();
+    const int c5 = opaque_u(c);
+    CHMC_TPROF(4);
+    for (int m = wv; m < sy.NOBS; m += NW) gld_fwd_ivl_body<M, RM>(sy, sl, w, 1, c5 * sy.NOBS + m);
+    wg_phase_sync();
+    const int c6 = opaque_u(c);
+    CHMC_TPROF(5);
+    for (int m = wv; m < sy.NOBS; m += NW) gld_bwd_ivl_body<M, RM, 0>(sy, sl, w, 1, c6 * sy.NOBS + m);
+    wg_phase_sync();
+    const int c7 = opaque_u(c);
+    for (int m = wv; m < sy.NOBS; m += NW) gld_bwd_ivl_body<M, RM, 1>(sy, sl, w, 1, c7 * sy.NOBS + m);
+    wg_phase_sync();
+    const int c8 = opaque_u(c);
+    CHMC_TPROF(6);
+    if (tid == 0) {
+      gld_ivl_finish_body<M, RM>(sy, sl, w, 1, c8);
+      KGldChain<M>{sy, sl, w, 1}(c8);
+    }
+    wg_phase_sync();
+    const int c9 = opaque_u(c);
+    CHMC_TPROF(7);
+    // ---- momentum correction p -= dh2_flow_mom_dmom @ (mu / dt), pg <- dh1_dpos; then P p and pg = P dh1_dpos in one pass
+    wg_rows(KMomFixInitPg{sy, sl, w, 1}, c9, sy.Q, NT);
+    wg_phase_sync();
+    const int c10 = opaque_u(c);
+    CHMC_TPROF(8);
+    if (wv == 0) {
+      jw_pb_body<RM, X, V, true>(sy, sl, w, 1, 256, c10);
+      wave_sync();
+      Work w1 = w, w2 = w;
+      w1.lampad = w.lampad2;
+      w2.cpad = w.cpad2;
+      if (tid == 0) KSymBlk<M, RM>{sy, sl, w1, 1, 0}(c10);
+      wave_sync();
+      solve_chain_body<M, RM, 1, 1>(sy, sl, w1, 1, 0, 0, c10);
+      wave_sync();
+      if (tid == 0) KSymBlk<M, RM>{sy, sl, w2, 1, 0}(c10);
+      wave_sync();
+      solve_chain_body<M, RM, 1, 1>(sy, sl, w2, 1, 0, 3, c10);
+    }
+    wg_phase_sync();
+    const int c11 = opaque_u(c);
+    CHMC_TPROF(9);
+    {
+      const KMuF<RM, X, 3> muf{sy, sl, w, 1};
+      for (int e = tid; e < sy.NOBS * X; e += NT) muf(c11 * sy.NOBS * X + e);
+    }
+    wg_phase_sync();
+    const int c12 = opaque_u(c);
+    {
+      const KUpdatePB<RM, X, V, 3, 1> up3{sy, sl, w, 1, 0, 0, CheckArgs{}};
+      for (int idx = tid; idx < ncol; idx += NT) (void)up3(c12, idx);
+    }
+    wg_phase_sync();
+    const int c13 = opaque_u(c);
+    // ---- reverse flow from the new point into work.qb, reverse retraction along J(new point), reversibility check
+    wg_rows(KFlow{sy, sl, w, 1, 1, 0, -1.0}, c13, sy.Q, NT);
+    wg_phase_sync();
+    const int c14 = opaque_u(c);
+    CHMC_TPROF(10);
+    retract_chain_body<M, RM, NW>(sy, sl, w, c14, 1, 1, ctol, ptol, dtol, max_iters, itb);
+    if (!chain_ok()) break;
+    const int c15 = opaque_u(c);
+    CHMC_TPROF(1);
+    {
+      const KRevDiff rd{sy, sl, w};
+      unsigned long long r = 0ULL;
+      for (int idx = tid; idx < (sy.Q + 1) / 2; idx += NT) {
+        const unsigned long long v = rd(c15, idx);
+        r = v > r ? v : r;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(r, off, 64);
+        r = o > r ? o : r;
+      }
+      if ((tid & 63) == 0) sRev[wv] = r;
+      wg_phase_sync();
+      if (tid == 0) {
+#pragma unroll
+        for (int k = 1; k < NW; ++k) r = sRev[k] > r ? sRev[k] : r;
+        w.rev[c15] = r;
+        rev_last = r;
+        KRevCheck{w, rev_tol}(c15);
+      }
+    }
+    if (!chain_ok()) break;
+    const int c16 = opaque_u(c);
+    // ---- A(dt/2) at the new point (momentum projected there: p - dt/2 pg), accept
+    wg_rows(KKickPg{sy, sl, w, 1, 0, kick}, c16, sy.Q, NT);
+    wg_phase_sync();
+    const int c17 = opaque_u(c);
+    if (tid == 0) KCommit{sl, w}(c17);
+    ++done;
+    wg_phase_sync();
+    CHMC_TPROF(11);
+  }
+  if (tid == 0) {
+    if (n_done) n_done[c] = done;
+    w.rev[c] = rev_last;  // (the reverse-check distance of the last step that reached the check)
   }
 }
 

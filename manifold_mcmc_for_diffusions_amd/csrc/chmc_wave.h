@@ -2170,12 +2170,11 @@ __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int w
 // J w from the compact rows (Slots::PB / LF), same interface and result arrays as k_jw_wave: inside observation
 // interval m the rows are LF[m][i] . PB[s], so the pass accumulates the row-independent y_m = sum_s PB[s] w_s (X values
 // per lane) and applies the frame once per interval: X V doubles of rows per step instead of up to RM V.
-template <int RM, int X, int V, bool TWO = false>
-__global__ void __launch_bounds__(256) k_jw_pb(Sys sy, Slots sl, Work w, int which, int vsel_) {
+template <int RM, int X, int V, bool TWO>
+__device__ __forceinline__ void jw_pb_body(const Sys& sy, const Slots& sl, const Work& w, int which, int vsel_, int wid) {
   const bool minv = (vsel_ & 256) != 0;
   const int vsel = vsel_ & 255;
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];  // work order: longest blocks first
   const int c = cbi / sy.K, b = cbi - c * sy.K;
@@ -2281,6 +2280,11 @@ __global__ void __launch_bounds__(256) k_jw_pb(Sys sy, Slots sl, Work w, int whi
     if (TWO) w.cpad2[cb * RM + i] = a2;
   }
 }
+template <int RM, int X, int V, bool TWO = false>
+__global__ void __launch_bounds__(256) k_jw_pb(Sys sy, Slots sl, Work w, int which, int vsel_) {
+  jw_pb_body<RM, X, V, TWO>(sy, sl, w, which, vsel_, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // Gradient of 1/2 log det Gram (value_and_grad of log_det_sqrt_gram, :812-820, :1143-1146), wave per (chain, block).
@@ -3291,14 +3295,13 @@ __global__ void __launch_bounds__(64, CHMC_GLD_LEAN_WAVES) k_gld_bwd_lean(Sys sy
 //   KGldIvlFinish       per (chain, block): sums, v_0 columns, dc/dz terms, work.gup (the tail of k_gld_bwd_lean)
 #define CHMC_GCQ_N(X, Z) (2 * (X) * (X) + (X) * (Z))  // per interval: C1 | C2 | Q0
 #define CHMC_GBW_N(X, Z) ((X) + 2 * (Z))               // per interval: x-bar handed on | z-bar (phase a) | z-bar (phase b)
+// (body: block `wid` of the work order by the calling wavefront; `wv_`: its slice of the LDS scratch, < 4)
 template <class M, int RM>
-__global__ void __launch_bounds__(256) k_gld_ivl_prologue(Sys sy, Slots sl, Work w, int which) {
+__device__ __forceinline__ void gld_ivl_prologue_body(const Sys& sy, const Slots& sl, const Work& w, int which, int wid, int wv_) {
   constexpr int X = M::X, Z = M::Z, V0 = M::V0;
   constexpr int NI = CHMC_IVL_N(X, Z), NC = CHMC_GCQ_N(X, Z);
   __shared__ double sm[4][RM * RM + RM * Z + 2 * RM * X + NI];
   const int lane = threadIdx.x & 63;
-  const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wid = blockIdx.x * (blockDim.x >> 6) + wv_;
   if (wid >= sy.B * sy.K) return;
   const int cbi = sy.order[wid];
   const int c = cbi / sy.K, b = cbi - c * sy.K;
@@ -3386,6 +3389,12 @@ __global__ void __launch_bounds__(256) k_gld_ivl_prologue(Sys sy, Slots sl, Work
     }
   }
 }
+template <class M, int RM>
+__global__ void __launch_bounds__(256) k_gld_ivl_prologue(Sys sy, Slots sl, Work w, int which) {
+  const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  gld_ivl_prologue_body<M, RM>(sy, sl, w, which, blockIdx.x * (blockDim.x >> 6) + wv_, wv_);
+}
+
 
 // (wid -> (chain, block, interval); false when the wavefront has nothing to do)
 __device__ inline bool gld_ivl_ids(const Sys& sy, const Work& w, int wid, int& c, int& b, int& j) {
@@ -3397,13 +3406,12 @@ __device__ inline bool gld_ivl_ids(const Sys& sy, const Work& w, int wid, int& c
 }
 
 template <class M, int RM>
-__global__ void __launch_bounds__(256) k_gld_fwd_ivl(Sys sy, Slots sl, Work w, int which) {
+__device__ __forceinline__ void gld_fwd_ivl_body(const Sys& sy, const Slots& sl, const Work& w, int which, int wid) {
   constexpr int X = M::X, V = M::V, Z = M::Z;
   constexpr int NC = CHMC_GCQ_N(X, Z);
   const int lane = threadIdx.x & 63;
-  const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int c, b, j;
-  if (!gld_ivl_ids(sy, w, blockIdx.x * (blockDim.x >> 6) + wv_, c, b, j)) return;
+  if (!gld_ivl_ids(sy, w, wid, c, b, j)) return;
   const BlockDesc bd = sy.blk[b];
   const int s_ = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
@@ -3509,17 +3517,21 @@ __global__ void __launch_bounds__(256) k_gld_fwd_ivl(Sys sy, Slots sl, Work w, i
     }
   }
 }
+template <class M, int RM>
+__global__ void __launch_bounds__(256) k_gld_fwd_ivl(Sys sy, Slots sl, Work w, int which) {
+  gld_fwd_ivl_body<M, RM>(sy, sl, w, which, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+}
+
 
 // PHASE 0: everything (Hessian contraction source, gradient entries without the incoming x-bar); PHASE 1: the incoming
 // x-bar's contribution only
 template <class M, int RM, int PHASE>
-__global__ void __launch_bounds__(256) k_gld_bwd_ivl(Sys sy, Slots sl, Work w, int which) {
+__device__ __forceinline__ void gld_bwd_ivl_body(const Sys& sy, const Slots& sl, const Work& w, int which, int wid) {
   constexpr int X = M::X, V = M::V, Z = M::Z, NXI = M::NXI;
   constexpr int NI = CHMC_IVL_N(X, Z), NC = CHMC_GCQ_N(X, Z), NB = CHMC_GBW_N(X, Z);
   const int lane = threadIdx.x & 63;
-  const int wv_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   int c, b, j;
-  if (!gld_ivl_ids(sy, w, blockIdx.x * (blockDim.x >> 6) + wv_, c, b, j)) return;
+  if (!gld_ivl_ids(sy, w, wid, c, b, j)) return;
   const BlockDesc bd = sy.blk[b];
   const int s_ = sl.cur[c] ^ which;
   const size_t cb = (size_t)c * sy.Kmax + b;
@@ -3740,12 +3752,16 @@ __global__ void __launch_bounds__(256) k_gld_bwd_ivl(Sys sy, Slots sl, Work w, i
     for (int i = 0; i < Z; ++i) gb[X + PHASE * Z + i] = zbt[i];
   }
 }
+template <class M, int RM, int PHASE>
+__global__ void __launch_bounds__(256) k_gld_bwd_ivl(Sys sy, Slots sl, Work w, int which) {
+  gld_bwd_ivl_body<M, RM, PHASE>(sy, sl, w, which, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+}
+
 
 template <class M, int RM>
-__global__ void __launch_bounds__(64) k_gld_ivl_finish(Sys sy, Slots sl, Work w, int which) {
+__device__ __forceinline__ void gld_ivl_finish_body(const Sys& sy, const Slots& sl, const Work& w, int which, int tid) {
   constexpr int X = M::X, Z = M::Z, U = M::U, V0 = M::V0;
   constexpr int NI = CHMC_IVL_N(X, Z), NB = CHMC_GBW_N(X, Z);
-  const int tid = blockIdx.x * 64 + threadIdx.x;
   if (tid >= sy.B * sy.K) return;
   const int c = tid / sy.K, b = tid - c * sy.K;
   if (!w.ok[c]) return;
@@ -3802,6 +3818,11 @@ __global__ void __launch_bounds__(64) k_gld_ivl_finish(Sys sy, Slots sl, Work w,
                                      pick(sl.grad, s_) + (size_t)c * sy.Q);
   for (int d = 0; d < U; ++d) w.gup[cb * U + d] = gu[d];
 }
+template <class M, int RM>
+__global__ void __launch_bounds__(64) k_gld_ivl_finish(Sys sy, Slots sl, Work w, int which) {
+  gld_ivl_finish_body<M, RM>(sy, sl, w, which, blockIdx.x * 64 + threadIdx.x);
+}
+
 
 // The same backward sweep for 16-row blocks.  With 16 rows the row loops of k_gld_bwd_wave cannot be unrolled (register
 // file) and, rolled, they index per-lane arrays at run time, which puts those arrays into scratch memory (4.0 ms per
@@ -4054,10 +4075,9 @@ __global__ void __launch_bounds__(256) k_gld_bwd_wave_ldsrows(Sys sy, Slots sl, 
 // lanes with shuffles, every lane solves the tiny core system redundantly, forms its block's multipliers and its
 // share of the u-columns of J^T lambda, which is reduced again.  Same template parameters as KSolveChain.
 template <class M, int RM, int SYM, int TGT>
-__global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work w, int which, int qsel, int psel) {
+__device__ __forceinline__ void solve_chain_body(const Sys& sy, const Slots& sl, const Work& w, int which, int qsel, int psel, int c) {
   constexpr int U = M::U;
   const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (c >= sy.B) return;
   if (TGT == 0 ? !newton_select(w, c, which, qsel) : !w.ok[c]) return;
   const int s = sl.cur[c] ^ which;
@@ -4149,20 +4169,27 @@ __global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work
     }
   }
 }
+template <class M, int RM, int SYM, int TGT>
+__global__ void __launch_bounds__(256) k_solve_chain_wave(Sys sy, Slots sl, Work w, int which, int qsel, int psel) {
+  solve_chain_body<M, RM, SYM, TGT>(sy, sl, w, which, qsel, psel,
+                                    blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // KGldPrep for 16-row blocks with the block over 16 lanes (four blocks per wavefront): lane r solves for column r of
 // D_b^-1 against the Cholesky factor parked in LDS (the per-column recurrences of cho_solve, same operation order), forms
 // row r of W_u = E C^-1 and column r of (G^-1)_bb = D_b^-1 - W_u E^T.  The one-lane functor keeps three 16 x 16 matrices in
 // scratch memory: 206-247 us per launch on the SIR single-block layout.
+// (body: the blocks tid0 .. tid0 + ntids - 1, ntids <= 4, on the 16-lane groups of the calling wavefront)
 template <class M, int RM>
-__global__ void __launch_bounds__(64) k_gld_prep_wave(Sys sy, Slots sl, Work w, int which) {
+__device__ __forceinline__ void gld_prep_body(const Sys& sy, const Slots& sl, const Work& w, int which, int tid0, int ntids) {
   static_assert(RM == 16, "rows over 16 lanes");
   constexpr int Z = M::Z, U = M::U;
   __shared__ double Ls[4][RM * RM], Es[4][RM * U], Ws[4][RM * U];
   const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  const int tid = blockIdx.x * 4 + g;
-  const bool live = tid < sy.B * sy.K;
+  const int tid = tid0 + g;
+  const bool live = g < ntids && tid < sy.B * sy.K;
   const int tc = live ? tid : 0;
   const int c = tc / sy.K, b = tc - c * sy.K;
   const bool act = live && w.ok[c] != 0;
@@ -4231,6 +4258,11 @@ __global__ void __launch_bounds__(64) k_gld_prep_wave(Sys sy, Slots sl, Work w, 
     w.gzd[(cb * RM + r) * Z + mz] = t;
   }
 }
+template <class M, int RM>
+__global__ void __launch_bounds__(64) k_gld_prep_wave(Sys sy, Slots sl, Work w, int which) {
+  gld_prep_body<M, RM>(sy, sl, w, which, blockIdx.x * 4, 4);
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // Newton iteration, everything between the Gram blocks and the J^T lambda column pass in ONE launch (blocks of at most 8

@@ -851,9 +851,9 @@ def test_compact_row_kernels_agree_with_the_stored_row_kernels_full_size(tmp_pat
 
 
 def test_time_parallel_scan_against_the_sequential_scan(monkeypatch):
-    """The SIR single-block layout three ways: (a) the default -- every Newton retraction of a chain in ONE launch by its own
-    workgroup (k_retract_chain: time-parallel scans of 512 segments, the chain iterates as long as IT needs) and the
-    time-parallel scan in the state evaluation; (b) CHMC_RETRACT_KERNEL=0: the lock-step rounds of round 3 with the
+    """The SIR single-block layout three ways: (a) the default -- the whole leapfrog step of a chain in ONE launch by its own
+    workgroup (k_traj_chain: retractions with time-parallel scans of 512 segments, every chain iterating as long as IT
+    needs, state evaluation and momentum projection in the same workgroup); (b) CHMC_RETRACT_KERNEL=0: the lock-step rounds of round 3 with the
     time-parallel scan (carried-over sweeps, chain mask 2); (c) also CHMC_PAR_SCAN=0: lock-step rounds with the sequential
     lane-per-block scan.  Statuses equal, Newton iteration counts equal (up to tolerance-edge counts: the scans agree to
     1e-12, not bitwise), positions to 1e-9, over 64 distinct chains x 6 steps with two chains whose retraction diverges."""
@@ -873,10 +873,10 @@ def test_time_parallel_scan_against_the_sequential_scan(monkeypatch):
         res = [ctx.leapfrog_step(dts, max_iters=15) for _ in range(6)]
         q1, p1, _, _ = ctx.get_state()
         d = ctx.diagnostics()
-        out.append((res, q1, p1, int(d["par_scan"][1:48].sum()), d["retract_kernel_launches"]))
+        out.append((res, q1, p1, int(d["par_scan"][1:48].sum()), d["retract_kernel_launches"] + d["traj_kernel_launches"]))
         ctx.close()
     (ra, qa, pa, na, ka), (rl, ql, pl, nl, kl), (rb, qb, pb, nb, kb) = out
-    assert ka == 12 and kl == 0 and kb == 0  # two retractions per step in one launch each, in the first context only
+    assert ka == 6 and kl == 0 and kb == 0  # one launch per step (k_traj_chain), in the first context only
     assert na > 0 and nl > 0 and nb == 0     # time-parallel sweeps ran in the first two contexts only
     for rx, qx in ((ra, qa), (rl, ql)):
         differ = 0
@@ -912,7 +912,7 @@ def test_results_do_not_depend_on_the_shard_size():
         return res, q1, p1
 
     whole = run(wl.ctx, slice(0, B))
-    assert wl.ctx.diagnostics()["retract_kernel_launches"] >= 6
+    assert wl.ctx.diagnostics()["traj_kernel_launches"] >= 3
     wl.ctx.close()
     n_ok = 0
     for h in range(2):

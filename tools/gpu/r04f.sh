@@ -1,0 +1,21 @@
+# per-chain trajectory kernel: SIR parity, A/B, bench
+export TMPDIR=/tmp
+R=$PWD
+O=$R/gpurun_out/r04f; mkdir -p $O; rm -rf $O/*
+timeout -k 10 180 python -m pytest tests/test_hip_parity.py -m gpu -x -q -k "test_baseline_config4_size_sir_s200" > $O/pytest_first.log 2>&1 || { tail -40 $O/pytest_first.log; exit 1; }
+tail -1 $O/pytest_first.log
+timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "sir or Sir or parallel or shard or adam or row_split or other_baseline or trajector" > $O/pytest_sir.log 2>&1 || { tail -60 $O/pytest_sir.log; exit 1; }
+tail -2 $O/pytest_sir.log
+timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-configs --config sir > $O/bench_sir.json 2> $O/e1.log || tail -5 $O/e1.log
+CHMC_RETRACT_KERNEL=0 timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-configs --config sir > $O/bench_sir_lockstep.json 2> $O/e1.log || tail -5 $O/e1.log
+timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-configs --config sir --chains-per-gpu 1024 > $O/bench_sir_1024.json 2> $O/e1.log || tail -5 $O/e1.log
+python - <<'PY'
+import glob, json
+for f in sorted(glob.glob('gpurun_out/r04f/bench_sir*.json')):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1]); c = d['config']
+        print(f.split('/')[-1], round(d['value']), round(d['ms_per_step'], 3), 'rounds', c.get('newton_rounds_per_step'), 'ok', round(c['step_success_rate'], 4), 'launches', c.get('launches_per_step'), c.get('value_repeats'))
+    except Exception as e:
+        print(f, 'unreadable', e)
+PY
+CHMC_HIP_LIBRARY=$R/build/libchmc_prof.so timeout -k 10 300 python tools/retract_prof.py 256 4 > $O/prof256.log 2>&1; tail -34 $O/prof256.log

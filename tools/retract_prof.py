@@ -23,6 +23,7 @@ for _ in range(2):  # burn-in as bench.py does
         r = wl.step(0.25, active=act)
         act &= (r["status"] == 0).astype(np.int32)
 d0 = ctx.diagnostics()["par_scan"].copy()
+x0 = ctx.diagnostics()["extra"].copy()
 t0 = time.perf_counter()
 its, steps = [], 0
 for _ in range(ntraj):
@@ -48,6 +49,15 @@ nsw = float((d[1:48] * (np.arange(47) % 16 + 1)).sum() + d[1:48].sum())  # sweep
 if sw.sum() > 0:
     for nm, t in zip(("recursion", "in-wave scan", "cross-wave", "new start states", "absorbing fronts", "hand-over", "final pass"), sw):
         print(f"    sweep: {nm:18s} {t/n_it:8.2f} us per iteration ({100*t/sw.sum():.0f} %)")
+xt = (ctx.diagnostics()["extra"] - x0).astype(float) * 0.16  # (ticks >> 4 at 100 MHz)
+if xt.sum() > 0:
+    names = ("A(dt/2) + flow", "both retractions", "state scan", "interval sums (state)", "combine / Cholesky / prep / prologue",
+             "grad log det forward", "grad log det backward (2 phases)", "finish + chain", "momentum fix", "J p + core solves",
+             "mu_F + J^T lambda + reverse flow", "reverse check + A(dt/2) + commit")
+    print(f"k_traj_chain phases, us per chain-step ({steps} chain-steps):")
+    for nm, t in zip(names, xt):
+        print(f"    {nm:40s} {t/steps:8.1f}  ({100*t/xt.sum():.0f} %)")
+    print(f"    {'total':40s} {xt.sum()/steps:8.1f}")
 ns = sweeps[:15] + sweeps[16:31] + sweeps[32:47]
 tot = ns.sum()
 print("sweeps to settle (histogram over scans, +1 final sweep each):", ns.tolist(), "mean", (ns * np.arange(1, 16)).sum() / max(tot, 1))
