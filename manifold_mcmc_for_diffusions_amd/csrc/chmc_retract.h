@@ -71,24 +71,109 @@ __device__ __forceinline__ void wg_phase_sync() {
 //       dc/dz rows sum_m LamF[m][i] Ws[m], one thread per entry, m descending and the components ascending as in
 //       newton_comb_body (same sums, same order);  (e) v_0 columns, observation-noise diagonal, identity padding, dc/du rows;
 //   (f) the block's LU, the chain's core system, the multipliers and mu_F on 16 lanes of wavefront 0 (newton_factor16).
-template <class M, int RM, int NW>
+// The Cholesky factorisation of a 16-row Gram block and everything KStateFactor derives from it, on 16 lanes of one wavefront
+// (lanes 0 .. 15 of the caller: row r per lane; the other lanes run along on identity rows): L (facD: lower triangle, zeros
+// above, the storage chol_lower leaves), the block's log-determinant share, E = D^-1 dc/du (forward / backward substitution with
+// L in LDS), C_b = (dc/du)^T E.  The factor itself is bitwise chol_lower<16> (same subtraction order); a single thread spends
+// 150 us on it with the 16 x 16 matrix in scratch memory (KStateFactor: fine as one of 256 lanes of a batched launch, not
+// on a chain's critical path).
+template <class M, int RM>
+__device__ __forceinline__ void state_factor16(const Sys& sy, const Slots& sl, const Work& w, int which, int c, bool act,
+                                               const double* Dsrc, const double* Jusrc, double* Lsh /* LDS, RM x RM */) {
+  static_assert(RM == 16, "rows over 16 lanes");
+  constexpr int U = M::U;
+  const int lane = threadIdx.x & 63, r = lane & 15;
+  const int s = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax;
+  double l[RM], e[U], ju[U];
+#pragma unroll
+  for (int k = 0; k < RM; ++k) l[k] = act ? Dsrc[r * RM + k] : (k == r ? 1.0 : 0.0);
+#pragma unroll
+  for (int d = 0; d < U; ++d) ju[d] = act ? Jusrc[r * U + d] : 0.0, e[d] = ju[d];
+  double ld = 0.0;
+#pragma unroll
+  for (int j = 0; j < RM; ++j) {
+    double t = l[j];
+#pragma unroll
+    for (int k = 0; k < RM; ++k)
+      if (k < j) t -= l[k] * readlane_d(l[k], j);
+    const double d = sqrt(readlane_d(t, j));
+    ld += log(fabs(d));
+    const double inv = 1.0 / d;
+    l[j] = r == j ? d : (r > j ? t * inv : 0.0);
+  }
+  if (lane < 16) {  // (the block's own lanes; the others hold identity rows)
+#pragma unroll
+    for (int k = 0; k < RM; ++k) Lsh[r * RM + k] = l[k];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // E = L^-T L^-1 dc/du, column-oriented: row k is final, then every other row takes its multiple of it
+#pragma unroll
+  for (int k = 0; k < RM; ++k) {
+    const double lkk = readlane_d(l[k], k);
+#pragma unroll
+    for (int d = 0; d < U; ++d) {
+      if (r == k) e[d] = e[d] / lkk;
+      const double bk = readlane_d(e[d], k);
+      if (r > k) e[d] -= l[k] * bk;
+    }
+  }
+#pragma unroll
+  for (int k = RM - 1; k >= 0; --k) {
+    const double lkk = readlane_d(l[k], k);
+    const double lkr = Lsh[k * RM + r];  // L[k][r], r < k
+#pragma unroll
+    for (int d = 0; d < U; ++d) {
+      if (r == k) e[d] = e[d] / lkk;
+      const double bk = readlane_d(e[d], k);
+      if (r < k) e[d] -= lkr * bk;
+    }
+  }
+  double Cb[U * U];
+#pragma unroll
+  for (int a = 0; a < U; ++a)
+#pragma unroll
+    for (int d = 0; d < U; ++d) Cb[a * U + d] = row16_sum(ju[a] * e[d]);
+  if (act) {
+    double* fd = pick(sl.facD, s) + cb * RM * RM + r * RM;
+#pragma unroll
+    for (int k = 0; k < RM; ++k) fd[k] = l[k];
+    double* E = pick(sl.E, s) + cb * RM * U + r * U;
+#pragma unroll
+    for (int d = 0; d < U; ++d) E[d] = e[d];
+    if (r == 0) {
+      pick(sl.ldb, s)[cb] = ld;
+#pragma unroll
+      for (int i = 0; i < U * U; ++i) w.Cb[cb * U * U + i] = Cb[i];
+    }
+  }
+}
+
+// STATE: the combine step of the state evaluation of slot `prev` (newton_comb_body<.., STATE>): the point's own frames (written to
+// Slots::LF), the symmetric Gram block (also to work.Dw), the rows' v_0 columns, the slot's dc/du rows and work.zbP; then the
+// block's Cholesky factor and what follows from it on 16 lanes (state_factor16) instead of the LU of a Newton iteration.
+template <class M, int RM, int NW, bool STATE = false>
 __device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, const Work& w, int prev, int qsel, int c,
                                                const BlockDesc& bd) {
   constexpr int X = M::X, Z = M::Z, U = M::U, V0 = M::V0, NT = 64 * NW;
   constexpr int NI = CHMC_IVL_N(X, Z);
   constexpr int MO = RM;  // observation intervals of a block with at most RM rows
-  __shared__ double Iv[MO][NI], LFp[MO][RM * X], LamF[MO + 1][RM * X], Ys[MO][RM * X], Dl[RM * RM], zl[RM * Z], JuS[RM * U];
+  __shared__ double Iv[MO][NI], LFp[STATE ? 1 : MO][RM * X], LamF[MO + 1][RM * X], Ys[MO][RM * X], Dl[RM * RM], zl[RM * Z],
+      JuS[RM * U];
+  static_assert(MO * RM * X >= RM * RM, "the Cholesky factor borrows Ys");
   const int tid = threadIdx.x;
   const int sp = sl.cur[c] ^ prev;
   const size_t cb = (size_t)c * sy.Kmax;
   const int S = sy.S, NV = sy.NV, nobs = bd.nobs;
-  const double* q = (qsel ? w.qb : pick(sl.q, sp ^ 1)) + (size_t)c * sy.Q;
-  const double* traj = w.trajw + (size_t)c * sy.TRJ + (size_t)bd.step0 * X;
-  const double* Jr = pick(sl.Jv, sp) + (size_t)c * RM * NV;
-  const double* LFr = pick(sl.LF, sp) + cb * sy.NOBS * RM * X;
+  const double* q = (STATE ? pick(sl.q, sp) : (qsel ? w.qb : pick(sl.q, sp ^ 1))) + (size_t)c * sy.Q;
+  const double* traj = (STATE ? pick(sl.traj, sp) : w.trajw) + (size_t)c * sy.TRJ + (size_t)bd.step0 * X;
+  double* Jr = pick(sl.Jv, sp) + (size_t)c * RM * NV;      // (STATE: the v_0 columns are written)
+  double* LFr = pick(sl.LF, sp) + cb * sy.NOBS * RM * X;   // (STATE: written)
   // (a)
   for (int e = tid; e < nobs * NI; e += NT) Iv[e / NI][e % NI] = w.ivl[cb * sy.NOBS * NI + e];
-  for (int e = tid; e < nobs * RM * X; e += NT) LFp[e / (RM * X)][e % (RM * X)] = LFr[e];
+  if constexpr (!STATE)
+    for (int e = tid; e < nobs * RM * X; e += NT) LFp[e / (RM * X)][e % (RM * X)] = LFr[e];
   __syncthreads();
   // (b) thread i: the adjoint row i from the end of the block back to its start; LamF[m] = the rows at the END of
   // interval m (after the rows that start there have been injected), LamF[MO] = the rows at the block's start
@@ -119,14 +204,16 @@ __device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, c
 #pragma unroll
     for (int a = 0; a < X; ++a) LamF[MO][i * X + a] = row[a];
   }
+  if constexpr (STATE) __syncthreads();  // (the point's own frames are the right-hand factor)
   // (c)
   for (int e = tid; e < nobs * RM * X; e += NT) {
     const int m = e / (RM * X), r = e - m * RM * X;
     const int jj = r / X, a = r - jj * X;
     double tt = 0.0;
 #pragma unroll
-    for (int a2 = 0; a2 < X; ++a2) tt += Iv[m][a * X + a2] * LFp[m][jj * X + a2];
+    for (int a2 = 0; a2 < X; ++a2) tt += Iv[m][a * X + a2] * (STATE ? LamF[m][jj * X + a2] : LFp[m][jj * X + a2]);
     Ys[m][r] = tt;
+    if constexpr (STATE) LFr[e] = LamF[m][r];  // the frame of interval m (Slots::LF)
   }
   __syncthreads();
   // (d) + (e)
@@ -141,9 +228,10 @@ __device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, c
       double dz[X * Z], dv0[X * V0];
       M::gx0_jac(dz, dv0);
       for (int d = 0; d < V0; ++d) {
-        double j0 = 0.0;
-        for (int a = 0; a < X; ++a) j0 += LamF[MO][i * X + a] * dv0[a * V0 + d];
-        tt += j0 * Jr[(size_t)jj * NV + d];
+        double j0 = 0.0, j1 = 0.0;
+        for (int a = 0; a < X; ++a) j0 += LamF[MO][i * X + a] * dv0[a * V0 + d], j1 += LamF[MO][jj * X + a] * dv0[a * V0 + d];
+        tt += j0 * (STATE ? j1 : Jr[(size_t)jj * NV + d]);
+        if (STATE && jj == 0) Jr[(size_t)i * NV + d] = j0;  // the rows' v_0 columns
       }
     }
     if (i == jj) {  // noise term on the observation rows (dc_dn_l * dc_dn_r, :772-791), identity padding
@@ -152,6 +240,7 @@ __device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, c
       if (i >= bd.nrows) tt = 1.0;
     }
     Dl[tid] = tt;
+    if constexpr (STATE) w.Dw[cb * RM * RM + tid] = tt;
   } else if (tid < RM * RM + RM * Z) {
     const int e = tid - RM * RM;
     const int i = e / Z, mz = e - i * Z;
@@ -171,6 +260,7 @@ __device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, c
       }
     }
     zl[e] = tt;
+    if constexpr (STATE) w.zbP[cb * RM * Z + e] = tt;
   }
   __syncthreads();
   if (tid < RM * U) {  // dc/du rows of the iterate through generate_z'(u)
@@ -189,10 +279,87 @@ __device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, c
       tt = i < bd.ny ? sigma_at(sy, q) * q[sy.U + sy.NV + bd.obs0 + i] : 0.0;
     }
     JuS[tid] = tt;
+    if constexpr (STATE) pick(sl.JuP, sp)[cb * RM * U + tid] = tt;
   }
   __syncthreads();
   // (f)
-  if (tid < 64) newton_factor16<M, RM, true, true>(sy, sl, w, prev, qsel, c, 0, tid < 16, Dl, JuS);
+  if (tid < 64) {
+    if constexpr (STATE) state_factor16<M, RM>(sy, sl, w, prev, c, tid < 16, Dl, JuS, &Ys[0][0]);  // (Ys is free: L goes there)
+    else newton_factor16<M, RM, true, true>(sy, sl, w, prev, qsel, c, 0, tid < 16, Dl, JuS);
+  }
+}
+
+// J p and J pg (k_jw_pb<.., TWO>) of the chain's block by the whole workgroup: the per-interval sums y_m = sum_s PB[s] w_s go to
+// the wavefronts (interval m to wavefront m mod NW), the frames are applied by 16 threads in jw_pb_body's order (m ascending).
+template <int RM, int X, int V, int NW>
+__device__ __forceinline__ void jw_pb_wg(const Sys& sy, const Slots& sl, const Work& w, int which, bool minv, int c,
+                                         const BlockDesc& bd) {
+  __shared__ double sY[RM][2][X];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (!w.ok[c]) return;  // (uniform)
+  const int s = sl.cur[c] ^ which;
+  const double* vct = pick(sl.p, s) + (size_t)c * sy.Q;
+  const double* vct2 = pick(sl.pg, s) + (size_t)c * sy.Q;
+  const size_t cb = (size_t)c * sy.Kmax;
+  const double* PB = pick(sl.PB, s) + ((size_t)c * sy.T * sy.S + bd.step0) * (X * V);
+  const double* LF = pick(sl.LF, s) + cb * sy.NOBS * RM * X;
+  const double* wv1 = vct + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const double* wv2 = vct2 + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  for (int m = wv; m < bd.nobs; m += NW) {
+    double y[X], y2[X];
+#pragma unroll
+    for (int a = 0; a < X; ++a) y[a] = 0.0, y2[a] = 0.0;
+    for (int k = m * sy.S + lane; k < (m + 1) * sy.S; k += 64) {
+      double pb[X * V], x[V], x2[V];
+      const double* src = PB + (size_t)k * (X * V);
+#pragma unroll
+      for (int e = 0; e < X * V; ++e) pb[e] = ld_stream(src + e);
+#pragma unroll
+      for (int d = 0; d < V; ++d) x[d] = wv1[(size_t)k * V + d], x2[d] = wv2[(size_t)k * V + d];
+#pragma unroll
+      for (int a = 0; a < X; ++a)
+#pragma unroll
+        for (int d = 0; d < V; ++d) {
+          y[a] += pb[a * V + d] * x[d];
+          y2[a] += pb[a * V + d] * x2[d];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < X; ++a) {
+      double v = y[a], v2 = y2[a];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64), v2 += __shfl_xor(v2, o, 64);
+      if (lane == 0) sY[m][0][a] = v, sY[m][1][a] = v2;
+    }
+  }
+  __syncthreads();
+  if (tid < RM) {
+    const int i = tid;
+    double a = 0.0, a2 = 0.0;
+    if (i < bd.nrows) {
+      for (int m = 0; m < bd.nobs; ++m) {
+        const double* lf = LF + ((size_t)m * RM + i) * X;
+#pragma unroll
+        for (int e = 0; e < X; ++e) {
+          const double f = lf[e];
+          a += f * sY[m][0][e];
+          a2 += f * sY[m][1][e];
+        }
+      }
+      if (bd.first) {  // v_0 columns: from the stored rows
+        const double* Jv = pick(sl.Jv, s) + (size_t)c * RM * sy.NV + (size_t)i * sy.NV;
+        for (int d = 0; d < sy.V0; ++d) a += Jv[d] * vct[sy.U + d], a2 += Jv[d] * vct2[sy.U + d];
+      }
+      const double* ju = pick(sl.JuP, s) + (cb * RM + i) * sy.U;
+      for (int d = 0; d < sy.U; ++d) a += ju[d] * (minv ? metric_inv_u(sy, vct, d) : vct[d]);
+      const double sg = sy.noisy ? sigma_at(sy, pick(sl.q, s) + (size_t)c * sy.Q) : 0.0;
+      if (sy.noisy && i < bd.ny) a += sg * vct[sy.U + sy.NV + bd.obs0 + i];
+      for (int d = 0; d < sy.U; ++d) a2 += ju[d] * (minv ? metric_inv_u(sy, vct2, d) : vct2[d]);
+      if (sy.noisy && i < bd.ny) a2 += sg * vct2[sy.U + sy.NV + bd.obs0 + i];
+    }
+    w.cpad[cb * RM + i] = a;
+    w.cpad2[cb * RM + i] = a2;
+  }
 }
 
 // The retraction of chain c by the calling workgroup (every thread calls it; returns with the chain's loop finished: status
@@ -415,13 +582,10 @@ __global__ void __launch_bounds__(64 * NW)
     wg_phase_sync();
     const int c4 = opaque_u(c);
     CHMC_TPROF(3);
+    newton_comb_wg<M, RM, NW, true>(sy, sl, w, 1, 0, c4, bd);  // ... and the block's Cholesky factor, E, C_b (16 lanes)
     if (wv == 0) {
-      newton_comb_body<M, RM, true, false>(sy, sl, w, 1, 0, c4, 0, bd);
       wave_sync();
-      if (tid == 0) {
-        KStateFactor<M, RM>{sy, sl, w, 1}(c4);  // (K == 1: work item c4 K + 0)
-        KStateChain<M>{sy, sl, w, 1}(c4);
-      }
+      if (tid == 0) KStateChain<M>{sy, sl, w, 1}(c4);
       wave_sync();
       gld_prep_body<M, RM>(sy, sl, w, 1, c4, 1);
       wave_sync();
@@ -453,8 +617,8 @@ __global__ void __launch_bounds__(64 * NW)
     wg_phase_sync();
     const int c10 = opaque_u(c);
     CHMC_TPROF(8);
+    jw_pb_wg<RM, X, V, NW>(sy, sl, w, 1, true, c10, bd);
     if (wv == 0) {
-      jw_pb_body<RM, X, V, true>(sy, sl, w, 1, 256, c10);
       wave_sync();
       Work w1 = w, w2 = w;
       w1.lampad = w.lampad2;

@@ -18,4 +18,4 @@ for f in sorted(glob.glob('gpurun_out/r04f/bench_sir*.json')):
     except Exception as e:
         print(f, 'unreadable', e)
 PY
-CHMC_HIP_LIBRARY=$R/build/libchmc_prof.so timeout -k 10 300 python tools/retract_prof.py 256 4 > $O/prof256.log 2>&1; tail -34 $O/prof256.log
+CHMC_HIP_LIBRARY=$R/build/libchmc_prof.so timeout -k 10 300 python tools/retract_prof.py 256 2 > $O/prof256.log 2>&1; tail -34 $O/prof256.log
