@@ -69,6 +69,10 @@ def parse():
                          "operator analogue of the reference's JAX path, eager and unjitted) at BASELINE.json configs[0]'s "
                          "shape (S = 50) on one core: about two minutes")
     ap.add_argument("--data-steps-per-obs", type=int, default=10000, help="fine grid of the simulated FHN data")
+    ap.add_argument("--collective", default="torch", choices=["torch", "cabi"],
+                    help="route of the one gather of samples: torch.distributed (backend nccl = RCCL) or the library's own "
+                         "C-ABI collective (chmc_comm_unique_id on rank 0, the 128-byte id broadcast through torch.distributed, "
+                         "chmc_comm_init, chmc_gather_samples = ncclAllGather between device buffers)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run (configs[1], one GPU) only: skip the short legs of the other single-GPU BASELINE shapes "
                          "that follow the headline's timed region (config.other_configs)")
@@ -413,11 +417,29 @@ def main():
     stats = []
     qd = torch.empty((B, ctx.Q), dtype=torch.float64, device=dev)  # gather staging
 
+    cabi_info = None
+    if a.collective == "cabi" and not emu:
+        # the library's own RCCL communicator: id from rank 0, broadcast as 128 bytes, one chmc_comm_init per rank
+        idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(ctx.comm_unique_id()), dtype=torch.uint8))
+        if world > 1:
+            import torch.distributed as dist
+            dist.broadcast(idt, src=0)
+        ctx.comm_init(bytes(idt.cpu().numpy().tobytes()), rank, world)
+        cabi_info = ctx.comm_info()  # (world, rank) read back from RCCL
+        gat = torch.empty((world, B, 7), dtype=torch.float64, device=dev)
+
     def gather_segment():
         # the single gather of samples of a sampling segment: traced variables per chain (u, v_0, hamiltonian)
         ctx.get_state_device(qd.data_ptr(), None)
         ham = torch.from_numpy(ctx.hamiltonian()[:, :1]).to(dev)
-        return D.gather_samples(torch.cat([qd[:, :6], ham], 1).contiguous(), equal_shards=True)
+        loc = torch.cat([qd[:, :6], ham], 1).contiguous()
+        if cabi_info is not None:
+            torch.cuda.synchronize(dev)  # (torch's stream has produced `loc`; the library gathers on its own stream)
+            ctx.gather_samples_device(loc.data_ptr(), loc.numel(), gat.data_ptr())
+            return gat.reshape(world * B, 7).cpu().numpy() if rank == 0 else None
+        return D.gather_samples(loc, equal_shards=True)
 
     iters_before = ctx.counters()["projection_iterations"]
     gather_segment()  # untimed: first use loads torch's copy / cat kernels and sets up the communicator's buffers
@@ -605,6 +627,10 @@ def main():
                 "launches_per_step": round(float(sum(nl_w)) / max(a.warmup, 1), 1),
                 "newton_rounds_per_step": rounds_per_step,
                 "collective_backend": D.backend_name(), "collective_world_size": D.world_size(),
+                "collective_route": ("C ABI: chmc_comm_init + chmc_gather_samples (ncclAllGather), RCCL communicator reports "
+                                     f"world {cabi_info[0]}, this rank {cabi_info[1]}") if cabi_info is not None
+                                    else "torch.distributed gather",
+                "cabi_comm_world_size": None if cabi_info is None else cabi_info[0],
                 "overlap_halves": int(os.environ.get("CHMC_HALVES", "-1")),
                 "kernel_classes_warmup": table,
             },

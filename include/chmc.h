@@ -292,11 +292,14 @@ int chmc_leapfrog_steps(chmc_ctx* ctx, const double* dt, const int* active, cons
  *   chmc_gather_samples : local_dev [count] doubles of this rank -> gathered_dev [world][count] on EVERY rank, rank-major
  *                         (equal shards); both are device buffers of the caller; enqueued on the context's stream and
  *                         complete when the call returns
+ *   chmc_comm_info      : world size and rank READ BACK from the communicator (ncclCommCount / ncclCommUserRank): what a
+ *                         launcher prints to show that the ranks it started really joined one RCCL communicator
  *   chmc_comm_destroy   : releases the communicator (chmc_destroy does the same for a context that still owns one).
  * N > 1 ranks have been rehearsed with gloo on CPU only so far (tests/test_distributed_gloo.py); see INTEGRATION.md. */
 int chmc_comm_unique_id(void* id128);
 int chmc_comm_init(chmc_ctx* ctx, const void* id128, int rank, int world);
 int chmc_gather_samples(chmc_ctx* ctx, const void* local_dev, long count, void* gathered_dev);
+int chmc_comm_info(chmc_ctx* ctx, int* world, int* rank);
 int chmc_comm_destroy(chmc_ctx* ctx);
 
 /* evaluation counters since creation: {constr, jacob_constr_blocks, lu_jacob_product_blocks, chol_gram_blocks,

@@ -88,6 +88,7 @@ SYMBOLS = [
     ("chmc_comm_unique_id", C.c_int, [C.c_void_p]),
     ("chmc_comm_init", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     ("chmc_gather_samples", C.c_int, [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]),
+    ("chmc_comm_info", C.c_int, [C.c_void_p, ip, ip]),
     ("chmc_comm_destroy", C.c_int, [C.c_void_p]),
     ("chmc_profile_enable", C.c_int, [C.c_int]),
     ("chmc_profile_stride", C.c_int, [C.c_int]),

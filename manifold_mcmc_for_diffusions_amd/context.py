@@ -394,6 +394,12 @@ class ChmcContext:
         check(self.L.chmc_gather_samples(self.h, C.c_void_p(local_dev_ptr), int(count), C.c_void_p(gathered_dev_ptr)),
               "chmc_gather_samples")
 
+    def comm_info(self):
+        """(world size, rank) read back from the RCCL communicator."""
+        wd, rk = C.c_int(0), C.c_int(0)
+        check(self.L.chmc_comm_info(self.h, C.byref(wd), C.byref(rk)), "chmc_comm_info")
+        return wd.value, rk.value
+
     def comm_destroy(self):
         check(self.L.chmc_comm_destroy(self.h), "chmc_comm_destroy")
 

@@ -1926,7 +1926,9 @@ __global__ void __launch_bounds__(64) k_gram_rows_mfma(Sys sy, Slots sl, Work w,
 }
 
 // Backward half of conditioned_diffusion_neg_log_dens_and_grad (:82-205): value and gradient of
-//   1/2 sum_t ((y_t - obs_func(x_t)) / sigma)^2 + T log sigma [+ 1/2 q^T q]        (fixed sigma, Y = 1)
+//   1/2 sum_t ((y_t - obs_func(x_t)) / sigma)^2 + T log sigma [+ 1/2 q^T q]        (Y = 1; sigma a number, or
+//   sigma = generate_sigma(u) = exp(u[Z]) with variable observation noise, :163-164, :183-187: the gradient then has the
+//   component d/du[Z] = T - sum_t r_t^2 [+ u[Z]])
 // by ONE adjoint sweep over the whole trajectory of a chain: one wavefront per chain, 64 consecutive steps per tile as
 // in k_rev_wave, a single adjoint row that picks up -r_t / sigma^2 * d obs_func at every observation time.
 template <class M>
@@ -1943,7 +1945,8 @@ __global__ void __launch_bounds__(256) k_nld_grad_wave(Sys sy, const double* qin
   ChainConsts<M> cc;
   cc.init(q, sy.dl);
   const int S = sy.S, ntile = (S + 63) >> 6;
-  const double is2 = 1.0 / (sy.sigma * sy.sigma);
+  const double sg = sigma_at(sy, q);  // a number, or exp(u[Z])
+  const double is2 = 1.0 / (sg * sg);
   double Lam[X], zacc[Z], vsq = 0.0, rsq = 0.0;
 #pragma unroll
   for (int a = 0; a < X; ++a) Lam[a] = 0.0;
@@ -2055,7 +2058,11 @@ __global__ void __launch_bounds__(256) k_nld_grad_wave(Sys sy, const double* qin
       if (g) g[d] = tt;
       qsq += q[d] * q[d];
     }
-    val[c] = 0.5 * rsq * is2 + sy.T * log(sy.sigma) + (gaussian ? 0.0 : 0.5 * qsq);
+    if (sy.varsig) {  // log sigma = u[Z]: d/du[Z] of 1/2 sum r^2 / sigma^2 + T log sigma
+      if (g) g[Z] = (gaussian ? 0.0 : q[Z]) + sy.T - rsq * is2;
+      qsq += q[Z] * q[Z];
+    }
+    val[c] = 0.5 * rsq * is2 + sy.T * log(sg) + (gaussian ? 0.0 : 0.5 * qsq);
   }
 }
 

@@ -11,8 +11,11 @@ def neg_log_dens_and_grad(model, obs_interval, num_steps_per_obs, y_seq, sigma, 
     T, S = y.shape[0], num_steps_per_obs
     dl = obs_interval / S
     q = torch.as_tensor(q, dtype=torch.float64).clone().requires_grad_(True)
-    U, V0, V = m.dim_z, m.dim_v_0, m.dim_v
+    var_sigma = isinstance(sigma, str)  # "variable": sigma = generate_sigma(u) = exp(u[dim_z]), dim_u = dim_z + 1 (:163-164)
+    U, V0, V = m.dim_z + int(var_sigma), m.dim_v_0, m.dim_v
     u, v_0, v_seq = q[:U], q[U:U + V0], q[U + V0:].reshape(T * S, V)
+    if var_sigma:
+        sigma = torch.exp(u[m.dim_z])
     z = m.generate_z(u)
     x = m.generate_x_0(z, v_0)
     obs = []
@@ -21,7 +24,8 @@ def neg_log_dens_and_grad(model, obs_interval, num_steps_per_obs, y_seq, sigma, 
         if (s + 1) % S == 0:
             obs.append(m.obs_func(x))
     y_mean = torch.stack(obs).reshape(-1, 1)
-    val = 0.5 * (((y - y_mean) / sigma) ** 2).sum() + T * torch.log(torch.tensor(float(sigma), dtype=torch.float64))
+    log_sigma = torch.log(sigma) if var_sigma else torch.log(torch.tensor(float(sigma), dtype=torch.float64))
+    val = 0.5 * (((y - y_mean) / sigma) ** 2).sum() + T * log_sigma
     if not use_gaussian_splitting:
         val = val + 0.5 * (q ** 2).sum()
     (g,) = torch.autograd.grad(val, q)

@@ -222,3 +222,41 @@ def test_adam_finder_objective_gradient_and_device_loop_against_the_oracle():
     assert (not np.isfinite(st[5, 0])) or st[5, 2] == 0.0
     assert (st[np.arange(B) != 5, 2] == 1.0).all()
     ctx.close()
+
+
+def test_adam_finder_variable_observation_noise_on_the_device():
+    """sigma = generate_σ_y(u) = exp(u[dim_z]) (scripts/run_sir_model_experiments.sh:7 runs the SIR experiment with it;
+    sde/mici_extensions.py:163-164, 183-187, 1706-1737): the comparator target / finder objective on device buffers --
+    value and gradient incl. the component d/du[dim_z] = T - sum r^2 + u[dim_z] -- against the autodiff restatement
+    (oracle/py, sigma="variable") to 1e-9, and the device-resident Adam loop finds states with mean squared residual < 1
+    that lie on the manifold, as the host loop (full state evaluation per iteration) does."""
+    import torch
+    from oracle.py.neg_log_dens import neg_log_dens_and_grad
+    from manifold_mcmc_for_diffusions_amd.context import ChmcContext
+    from manifold_mcmc_for_diffusions_amd import init
+    counts = np.array([3.0, 8.0, 28.0, 75.0, 221.0, 281.0])
+    B, T, S = 7, len(counts), 8
+    ctx = ChmcContext("sir", 1.0, S, T, counts, sigma="variable", num_chains=B)
+    assert ctx.U == 5 and ctx.variable_sigma
+    nuv = ctx.Q - T
+    rng = np.random.default_rng(4)
+    u_v = 0.5 * rng.standard_normal((B, nuv))
+    dev = torch.device("cuda", 0)
+    ud, gd = torch.from_numpy(u_v).to(dev), torch.empty((B, nuv), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    val = init.init_objective_and_grad_device(ctx, ud.data_ptr(), gd.data_ptr())
+    g = gd.cpu().numpy()
+    for c in range(B):
+        vo, go = neg_log_dens_and_grad("sir", 1.0, S, counts, "variable", u_v[c], False)
+        assert abs(val[c] - vo) <= 1e-10 * max(1.0, abs(vo)), (c, val[c], vo)
+        assert np.abs(g[c] - go).max() <= 1e-9 * max(1.0, np.abs(go).max()), (c, np.abs(g[c] - go).argmax())
+    # host entry point (chmc_neg_log_dens_and_grad) agrees with the device one
+    v2, g2 = ctx.neg_log_dens_and_grad(u_v)
+    np.testing.assert_allclose(v2, val, rtol=1e-14)
+    np.testing.assert_allclose(g2, g, rtol=1e-13, atol=1e-13)
+    for resident in (True, False):
+        q1, xo1, tries = init.find_initial_states_by_gradient_descent_noisy_system(
+            ctx, np.random.default_rng(12), adam_step_size=0.1, max_iters=3000, device_resident=resident)
+        sig = np.exp(q1[:, ctx.U - 1])
+        assert (np.mean(q1[:, -T:] ** 2, 1) < 1.0).all() and np.abs(ctx.constr()).max() < 1e-9 * max(1.0, sig.max())
+    ctx.close()

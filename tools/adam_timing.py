@@ -1,5 +1,5 @@
 """Adam-based initial states for the boarding-school SIR configuration (BASELINE.json configs[3]): device-resident loop
-against the host loop.  usage: python tools/adam_timing.py [chains] [host: 0/1]"""
+against the host loop.  usage: python tools/adam_timing.py [chains] [host: 0/1] [sigma: 1.0 | variable]"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
@@ -9,8 +9,11 @@ from manifold_mcmc_for_diffusions_amd import init
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 host = len(sys.argv) > 2 and sys.argv[2] == "1"
+sigma = sys.argv[3] if len(sys.argv) > 3 else "1.0"
+sigma = "variable" if sigma == "variable" else float(sigma)
 y = np.asarray(BOARDING_SCHOOL_COUNTS, dtype=np.float64)
-ctx = ChmcContext("sir", 1.0, 200, len(y), y, sigma=1.0, num_chains=B)
+ctx = ChmcContext("sir", 1.0, 200, len(y), y, sigma=sigma, num_chains=B)
+print(f"sigma = {sigma}")
 for label, dr in (("device-resident", True),) + ((("host loop", False),) if host else ()):
     t0 = time.perf_counter()
     q, xo, tries = init.find_initial_states_by_gradient_descent_noisy_system(
