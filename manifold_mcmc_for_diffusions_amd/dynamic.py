@@ -163,7 +163,7 @@ def sample_dynamic_chmc(ctx, n_iter, step_size, seed, n_adapt=0, chain_offset=0,
     from .sampling import DualAveragingStepSize, PerChainDualAveragingStepSize, _mean_over_all_chains
     tr = DynamicTransition(ctx, step_size, seed, chain_offset=chain_offset, total_chains=total_chains, **kw)
     B = ctx.B
-    adapter = None
+    adapter, adapted = None, None
     if n_adapt > 0:
         adapter = PerChainDualAveragingStepSize(step_size, B) if per_chain_step_size else DualAveragingStepSize(step_size)
     heads = np.empty((n_iter, B, n_head))
@@ -205,7 +205,8 @@ def sample_dynamic_chmc(ctx, n_iter, step_size, seed, n_adapt=0, chain_offset=0,
             if per_chain_step_size:
                 tr.step_size = adapter.update(st["accept_stat"])  # [B]: every chain its own step size during warm-up
                 if it == n_adapt - 1:
-                    tr.step_size = _mean_over_all_chains(adapter.final().sum(), B)
+                    adapted = np.asarray(adapter.final(), dtype=np.float64).copy()  # per chain, before averaging
+                    tr.step_size = _mean_over_all_chains(adapted.sum(), B)
             else:
                 tr.step_size = adapter.update(acc)
                 if it == n_adapt - 1:
@@ -214,7 +215,7 @@ def sample_dynamic_chmc(ctx, n_iter, step_size, seed, n_adapt=0, chain_offset=0,
             callback(it, heads[it], acc, float(np.mean(tr.step_size)), st)
     n_main = max(n_iter - n_adapt, 1)
     out = dict(heads=heads, accept_stat=acc_hist, step_size=eps_hist, n_step=nstep_hist, integrator_error=err_hist,
-               final_step_size=float(np.mean(tr.step_size)), chain_outcomes_dynamic=outcome,
+               final_step_size=float(np.mean(tr.step_size)), adapted_step_sizes=adapted, chain_outcomes_dynamic=outcome,
                per_chain={k: v / n_main for k, v in per_chain.items()})
     if writer is not None:
         from .traces import save_summary

@@ -55,6 +55,17 @@ def test_posterior_and_sampler_statistics_with_the_dynamic_transition(tmp_path):
     # starts, a few of them in stiff regions with tiny adapted steps, that mean is shorter than what a healthy chain would
     # pick, hence an accept statistic above the 0.8 target (the notebook's two chains: 0.83)
     assert 0.7 < res["accept_stat"][150:].mean() < 0.97
+    #  the step size itself, not only its consequence: the main phase's step size is the arithmetic mean of the
+    # chains' adapted ones, and it must be of the size the bulk of the chains picked -- a mean dragged far below the
+    # median by tiny steps (or a main phase that simply runs too small a step) would pass an accept window alone
+    eps = res.get("adapted_step_sizes")
+    if eps is not None:
+        qs = np.quantile(eps, [0.0, 0.1, 0.5, 0.9, 1.0])
+        print("per-chain adapted step sizes: min / 10 % / median / 90 % / max =", np.round(qs, 4), "mean", round(float(eps.mean()), 4),
+              "main phase", round(res["final_step_size"], 4), "accept", round(float(res["accept_stat"][150:].mean()), 3),
+              "n_step", round(float(res["n_step"][150:].mean()), 1))
+        assert abs(res["final_step_size"] - eps.mean()) <= 1e-12 * eps.mean()
+        assert 0.6 * qs[2] < res["final_step_size"] < 1.5 * qs[2], (qs, res["final_step_size"])
     assert 15.0 < res["n_step"][150:].mean() < 45.0
     assert res["integrator_error"][150:].mean() < 0.4
     for r in rows:
