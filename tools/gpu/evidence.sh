@@ -6,10 +6,10 @@ export TMPDIR=/tmp
 R=$PWD
 TAG=${1:-r04}
 O=$R/gpurun_out/${TAG}_evidence; mkdir -p $O; rm -rf $O/*
-P=$R/profiles
+P=$O/profiles; mkdir -p $P   # (only gpurun_out/ travels back: copy $P/* into profiles/ afterwards)
 bash tools/gpu/pmc_traffic.sh $TAG > $O/pmc.log 2>&1 || { tail -20 $O/pmc.log; exit 1; }
 tail -4 $O/pmc.log
-cp $P/traffic.json $O/traffic.json
+cp $R/profiles/traffic.json $R/profiles/${TAG}_pmc_*_by_kernel.csv $P/
 timeout -k 10 500 python bench.py > $O/bench_default.json 2> $O/bench_default.err || tail -5 $O/bench_default.err
 cp $O/bench_default.json $P/${TAG}_bench_default.json
 for cfg in sir fhn_noiseless; do

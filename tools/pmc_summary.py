@@ -27,7 +27,7 @@ CLASS_OF = [  # substring of the kernel name -> profiling class of include/chmc.
     ("k_newton_lean<chmc::FhnModel, 8, true, true>", "state_blk"), ("k_newton_lean<chmc::SirModel, 8, true, true>", "state_blk"),
     ("k_newton_lean<chmc::FhnNbModel, 6, true, true>", "state_blk"), ("k_newton_lean<chmc::FhnNbModel, 8, true, true>", "state_blk"),
     ("k_newton_ivl<chmc::SirModel, true>", "state_blk"), ("k_newton_comb<chmc::SirModel, 16, true", "state_blk"),
-    ("k_newton_lean", "newton_blk"), ("k_newton_ivl", "newton_blk"), ("k_newton_comb", "newton_blk"), ("k_retract_chain", "newton_blk"),
+    ("k_newton_lean", "newton_blk"), ("k_newton_ivl", "newton_blk"), ("k_newton_comb", "newton_blk"), ("k_retract_chain", "newton_blk"), ("k_traj_chain", "newton_blk"),
     ("k_newton_factor_wave", "sym_blk"), ("k_gram_rows", "newton_blk"), ("KUpdatePB", "update"), ("KMuF", "solve_chain"),
     ("k_jw_pb", "jacob_vec"), ("KRowsFromPB", "state_blk"),
     ("k_rev_wave_ldsrows<chmc::SirModel, 16, 1", "newton_blk"), ("k_rev_wave_ldsrows<chmc::SirVsModel, 16, 1", "newton_blk"),
