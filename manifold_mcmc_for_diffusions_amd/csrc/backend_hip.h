@@ -48,6 +48,11 @@ static int dev_init(int device) {
   g_first_err = hipSuccess;
   return 0;
 }
+static int dev_num_cus() {
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, g_device) != hipSuccess || n <= 0) n = 256;
+  return n;
+}
 static void* dev_alloc(size_t bytes) {
   void* p = nullptr;
   note(hipMalloc(&p, bytes ? bytes : 8));

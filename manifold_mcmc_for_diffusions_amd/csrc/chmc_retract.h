@@ -30,6 +30,14 @@ namespace chmc {
 #ifndef CHMC_RETRACT_WAVES
 #define CHMC_RETRACT_WAVES 8  // 512 threads: two wavefronts per SIMD of the chain's CU, up to 256 registers each
 #endif
+// Segmentation of a chain's time-parallel scans: 64 x this many segments, on the first wavefronts of the workgroup -- and in
+// the batched path of the same layouts (k_fwd_par<.., CHMC_CHAIN_SCAN_WAVES>), which must integrate the same segments to give
+// the same bits.  Measured (batched path, boarding-school SIR, steps/s at 256 / 1 024 chains): 2: 65.8 k / 123.8 k, 4: 69.4 k /
+// 122.3 k, 8: 55.2 k / 94.8 k -- 512 segments cost the throughput regime a quarter (junction-scan and barrier work grows with
+// the wavefronts, the exact prefix of a diverging chain's scan advances one segment per sweep); per-chain kernel: see DESIGN 4.2.
+#ifndef CHMC_CHAIN_SCAN_WAVES
+#define CHMC_CHAIN_SCAN_WAVES 4
+#endif
 
 // -DCHMC_RETRACT_PROF: thread 0 of every workgroup adds the 100 MHz ticks of each phase to work.nfallback[48 ..] (diagnostic
 // build only, tools/retract_prof.py): [48] scan [49] sums [50] combine [51] update + check [52] iterations [53] retractions
@@ -362,6 +370,23 @@ __device__ __forceinline__ void jw_pb_wg(const Sys& sy, const Slots& sl, const W
   }
 }
 
+// The per-chain phases as kernels of their own (one workgroup per chain), for the lock-step path of the same layouts: with them
+// a batched launch does the arithmetic of the per-chain kernels bit for bit, so the choice between the two execution models
+// (per-chain workgroups for up to a few chains per CU, batched launches for throughput beyond that) never changes a result.
+template <class M, int RM, int NW, bool STATE>
+__global__ void __launch_bounds__(64 * NW) k_newton_comb_wg(Sys sy, Slots sl, Work w, int which, int qsel) {
+  const int c = blockIdx.x;
+  if (c >= sy.B) return;
+  if (STATE ? !w.ok[c] : !newton_select(w, c, which, qsel)) return;  // (uniform over the workgroup)
+  newton_comb_wg<M, RM, NW, STATE>(sy, sl, w, which, qsel, c, sy.blk[0]);
+}
+template <int RM, int X, int V, int NW>
+__global__ void __launch_bounds__(64 * NW) k_jw_pb_wg(Sys sy, Slots sl, Work w, int which) {
+  const int c = blockIdx.x;
+  if (c >= sy.B) return;
+  jw_pb_wg<RM, X, V, NW>(sy, sl, w, which, true, c, sy.blk[0]);
+}
+
 // The retraction of chain c by the calling workgroup (every thread calls it; returns with the chain's loop finished: status
 // in work.nstat / ok / status, counts in work.iters and *iters_dst, the last iterate's trajectory in work.trajw).
 template <class M, int RM, int NW>
@@ -405,7 +430,8 @@ __device__ __forceinline__ void retract_chain_body(const Sys& sy, const Slots& s
       double Ul[X];
       int s0;
       bool have;
-      (void)fwd_par_sweeps<M, RM, NW, 8>(sy, w, bd, q, sy.xobs + (size_t)ca * sy.T * X, traj, guess, out, 64 * NW + 2,
+      (void)fwd_par_sweeps<M, RM, CHMC_CHAIN_SCAN_WAVES, 0, NW>(sy, w, bd, q, sy.xobs + (size_t)ca * sy.T * X, traj, guess, out,
+                                                                64 * CHMC_CHAIN_SCAN_WAVES + 2,
                                          it == 0 ? 2 : 1, Ul, s0, have);
       if (tid == 0)
         for (int i = bd.nrows; i < RM; ++i) out[i] = 0.0;  // padded constraint slots
@@ -570,8 +596,8 @@ __global__ void __launch_bounds__(64 * NW)
       double Ul[X];
       int s0;
       bool have;
-      (void)fwd_par_sweeps<M, RM, NW, 8>(sy, w, bd, q1, sy.xobs + (size_t)c2 * sy.T * X, traj1, w.trajw + toff, out,
-                                         64 * NW + 2, 3, Ul, s0, have);
+      (void)fwd_par_sweeps<M, RM, CHMC_CHAIN_SCAN_WAVES, 0, NW>(sy, w, bd, q1, sy.xobs + (size_t)c2 * sy.T * X, traj1, w.trajw + toff, out,
+                                         64 * CHMC_CHAIN_SCAN_WAVES + 2, 3, Ul, s0, have);
       if (tid == 0)
         for (int i = bd.nrows; i < RM; ++i) out[i] = 0.0;
     }

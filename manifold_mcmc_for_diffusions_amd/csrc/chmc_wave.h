@@ -4892,11 +4892,14 @@ __global__ void __launch_bounds__(STORE ? 64 * (1 + CHMC_SCAN_HELPERS) : 64)
 // transition matrices, no junction system) from the settled start states.  PRE > 0: a segment of at most PRE steps keeps its
 // noise increments in registers for all sweeps (they do not change; the per-step global load was exposed latency with two
 // wavefronts per SIMD) and the step loop is unrolled with predicates.
-template <class M, int RM, int W, int PRE = 0>
+// WG > W: the calling workgroup has WG wavefronts of which the first W integrate (the per-chain kernels: 8 wavefronts, 256
+// segments on 4 of them); the others only keep the workgroup barriers and the loop control in step.
+template <class M, int RM, int W, int PRE = 0, int WG = W>
 __device__ __forceinline__ bool fwd_par_sweeps(const Sys& sy, const Work& w, const BlockDesc& bd, const double* q,
                                                const double* xobs, double* traj, const double* guess, double* out, int MAXS,
                                                int gsel, double (&Ul)[M::X], int& s0r, bool& haver) {
   constexpr int X = M::X, V = M::V;
+  static_assert(WG >= W && (WG == W || W > 1), "idle wavefronts need the cross-wavefront form");
   const int lane = threadIdx.x & 63;
   const int wv = W > 1 ? (int)(threadIdx.x >> 6) : 0;  // wavefront of the workgroup
   const int gl = W > 1 ? (int)threadIdx.x : lane;      // segment of the block
@@ -4907,6 +4910,27 @@ __device__ __forceinline__ bool fwd_par_sweeps(const Sys& sy, const Work& w, con
       sUn[W > 1 ? W : 1][M::X];
   __shared__ int sFlag[W > 1 ? W : 1], sFront[W > 1 ? W : 1][1 + 2 * M::X], sStuck[W > 1 ? W : 1];
   __shared__ double sTv[W > 1 ? W : 1][M::X];
+  if (WG > W && wv >= W) {  // idle wavefront: the same barriers (B), (B'), (C) per sweep, the same exit
+    bool settled_ = false;
+    for (int sweep = 0; sweep < MAXS && !settled_; ++sweep) {
+      __syncthreads();  // (B)
+      if (M::NABS > 0) {
+        int any = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k) any |= sStuck[k];
+        if (any) __syncthreads();  // (B')
+      }
+      __syncthreads();  // (C)
+      int any = 0;
+#pragma unroll
+      for (int k = 0; k < W; ++k) any |= sFlag[k];
+      settled_ = !any;
+    }
+#pragma unroll
+    for (int a = 0; a < X; ++a) Ul[a] = 0.0;
+    s0r = 0, haver = false;
+    return settled_;
+  }
   const int S = sy.S, L = bd.nsteps;
   const double* vbase = q + sy.U + sy.V0 + (size_t)bd.step0 * V;
   const double* nn = q + sy.U + sy.NV;
@@ -5288,7 +5312,11 @@ __global__ void __launch_bounds__(64 * W) k_fwd_par(Sys sy, Slots sl, Work w, in
   double Ul[X];  // start state of this lane's segment
   int s0 = 0;
   bool have = false;
-  const bool converged = fwd_par_sweeps<M, RM, W>(sy, w, bd, q, xobs, traj, guess, out, MAXS, gsel, Ul, s0, have);
+  // (one 16-row block per chain: the layouts of the per-chain kernels, chmc_retract.h, whose arithmetic this launch repeats
+  // bit for bit -- no sequential fallback outside a loop, the sweeps go on until settled, as there)
+  const bool chain16 = RM > 8 && sy.Kmax == 1;
+  const bool converged = fwd_par_sweeps<M, RM, W>(sy, w, bd, q, xobs, traj, guess, out,
+                                                  (chain16 && !apend) ? 64 * W + 2 : MAXS, gsel, Ul, s0, have);
   if (apend) {
     if (!converged) {
       // keep the junction states for the next round's sweeps (the guess is then this buffer: gsel 1)

@@ -6,6 +6,7 @@
 #include <cstring>
 static int dev_set(int) { return 0; }
 static int dev_init(int) { return 0; }
+static int dev_num_cus() { return 1; }
 static void* dev_alloc(size_t bytes) { return calloc(bytes ? bytes : 8, 1); }
 static void dev_free(void* p) { free(p); }
 static void dev_zero(void* p, size_t bytes) { memset(p, 0, bytes); }

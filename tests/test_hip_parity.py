@@ -878,26 +878,76 @@ def test_time_parallel_scan_against_the_sequential_scan(monkeypatch):
     (ra, qa, pa, na, ka), (rl, ql, pl, nl, kl), (rb, qb, pb, nb, kb) = out
     assert ka == 6 and kl == 0 and kb == 0  # one launch per step (k_traj_chain), in the first context only
     assert na > 0 and nl > 0 and nb == 0     # time-parallel sweeps ran in the first two contexts only
-    for rx, qx in ((ra, qa), (rl, ql)):
-        differ = 0
-        for x, y in zip(rx, rb):
-            np.testing.assert_array_equal(x["status"], y["status"])
-            differ += int((x["iters_fwd"] != y["iters_fwd"]).sum() + (x["iters_bwd"] != y["iters_bwd"]).sum())
-        assert differ <= 2  # (a count may differ on the edge of a tolerance)
-        if differ == 0:
-            assert np.abs(qx - qb).max() <= 1e-9 * max(1.0, np.abs(qb).max())
+    # (a) = (b) BIT FOR BIT: the batched path of this layout runs the per-chain kernels' arithmetic (512 segments per chain,
+    # workgroup-parallel combine, 16-lane factorisations), so the execution model -- one workgroup per chain or batched
+    # launches, chosen by the number of chains per CU -- never changes a result
+    for x, y in zip(ra, rl):
+        for k in x:
+            np.testing.assert_array_equal(x[k], y[k], err_msg=k)
+    np.testing.assert_array_equal(qa, ql)
+    np.testing.assert_array_equal(pa, pl)
+    # against the sequential scan: statuses equal, counts equal up to tolerance-edge cases, positions to 1e-9
+    differ = 0
+    for x, y in zip(ra, rb):
+        np.testing.assert_array_equal(x["status"], y["status"])
+        differ += int((x["iters_fwd"] != y["iters_fwd"]).sum() + (x["iters_bwd"] != y["iters_bwd"]).sum())
+    assert differ <= 2  # (a count may differ on the edge of a tolerance)
+    if differ == 0:
+        assert np.abs(qa - qb).max() <= 1e-9 * max(1.0, np.abs(qb).max())
     assert (ra[0]["status"][[9, 33]] > 0).all()
 
 
-def test_results_do_not_depend_on_the_shard_size():
+@pytest.mark.parametrize("T,S,B,var_sigma", [(14, 8, 37, False), (12, 16, 9, True), (14, 200, 40, False)])
+def test_per_chain_kernels_equal_the_batched_path_bitwise(monkeypatch, T, S, B, var_sigma):
+    """Layouts with one 16-row block per chain (SIR, R >= T): k_traj_chain (default: one workgroup per chain, whole steps)
+    against the batched lock-step path of the same layouts (CHMC_RETRACT_KERNEL=0: k_fwd_par<8>, k_newton_ivl,
+    k_newton_comb_wg, KUpdatePB, KCheck, ... as separate launches): positions, momenta, statuses, iteration counts,
+    reverse-check distances and Hamiltonians bitwise equal over 4 steps, with masked and failing chains, short and long
+    blocks, fixed and variable observation noise."""
+    case = make_case("sir", T, S, T, True, B=B, seed=61, obs_interval=0.25, var_sigma=var_sigma)
+    rng = np.random.default_rng(8)
+    p = rng.standard_normal(case["q"].shape)
+    qq, xx = np.repeat(case["q"][:1], B, 0), np.repeat(case["x_obs"][:1], B, 0)
+    dts = np.where(np.arange(B) % 2 == 0, 1.0, -1.0) * (0.01 + 0.03 * rng.random(B))
+    dts[[2, B - 2]] = 5.0
+    act = np.ones(B, dtype=np.int32)
+    act[[1, B - 1]] = 0
+    out = []
+    for retract in ("1", "0"):
+        monkeypatch.setenv("CHMC_RETRACT_KERNEL", retract)
+        ctx = make_ctx(case)
+        assert ctx.RM == 16 and ctx.K == [1]
+        ctx.set_state(qq, p, xx, 0)
+        ctx.project_onto_cotangent_space()
+        res = [ctx.leapfrog_step(dts, active=act if k == 0 else None, max_iters=15) for k in range(3)]
+        res.append(ctx.leapfrog_steps(dts, 2, max_iters=15))
+        q1, p1, _, _ = ctx.get_state()
+        d = ctx.diagnostics()
+        out.append((res, q1, p1, ctx.hamiltonian(), d["traj_kernel_launches"]))
+        ctx.close()
+    (ra, qa, pa, ha, ka), (rb, qb, pb, hb, kb) = out
+    assert ka == 4 and kb == 0
+    for x, y in zip(ra, rb):
+        for k in x:
+            np.testing.assert_array_equal(x[k], y[k], err_msg=k)
+    np.testing.assert_array_equal(qa, qb)
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_array_equal(ha, hb)
+    assert (ra[0]["status"][[1, B - 1]] == -1).all() and (ra[0]["status"][[2, B - 2]] > 0).all()
+    assert (ra[-1]["n_done"] == 2).sum() >= B // 2
+
+
+@pytest.mark.parametrize("B,shards", [(256, 2), (576, 3)])
+def test_results_do_not_depend_on_the_shard_size(B, shards):
     """SURVEY 4 (viii) / BASELINE configs[3] (1 024 SIR chains sharded over 4 GPUs): a chain's results must not depend on
-    how many chains share its context.  256 boarding-school chains (Adam-based initial states, S = 200, one 14-row block)
-    stepped as ONE context and as TWO contexts of 128 with the default switches: positions, momenta, statuses, iteration
-    counts and reverse-check distances after 3 steps agree BITWISE (every kernel choice follows from the layout, the
-    retraction kernel and the scans use a fixed number of segments per chain, every reduction has a fixed order)."""
+    how many chains share its context.  Boarding-school chains (Adam-based initial states, S = 200, one 14-row block)
+    stepped as ONE context and as `shards` contexts of B / shards chains with the default switches: positions, momenta,
+    statuses, iteration counts and reverse-check distances after 3 steps agree BITWISE (every kernel choice that changes
+    arithmetic follows from the layout; the scans use a fixed number of segments per chain; every reduction has a fixed
+    order).  576 chains: the one context runs the BATCHED path (more than two chains per compute unit), its shards of 192 the
+    per-chain kernels -- the two execution models give the same bits."""
     from manifold_mcmc_for_diffusions_amd.workload import SirWorkload
     from manifold_mcmc_for_diffusions_amd.context import ChmcContext
-    B = 256
     wl = SirWorkload(B, num_steps_per_obs=200)
     q0, _, xo, _ = wl.ctx.get_state()
     rng = np.random.default_rng(31)
@@ -907,22 +957,24 @@ def test_results_do_not_depend_on_the_shard_size():
     def run(ctx, sl):
         ctx.set_state(q0[sl], p0[sl], xo[sl], 0)
         ctx.project_onto_cotangent_space()
+        d0 = ctx.diagnostics()["traj_kernel_launches"]
         res = [ctx.leapfrog_step(dts[sl], **wl.solver) for _ in range(3)]
         q1, p1, _, _ = ctx.get_state()
-        return res, q1, p1
+        return res, q1, p1, ctx.diagnostics()["traj_kernel_launches"] - d0
 
     whole = run(wl.ctx, slice(0, B))
-    assert wl.ctx.diagnostics()["traj_kernel_launches"] >= 3
+    assert whole[3] == (3 if B <= 512 else 0)  # (MI355X: 256 compute units; per-chain kernels up to two chains per CU)
     wl.ctx.close()
-    n_ok = 0
-    for h in range(2):
-        sl = slice(h * B // 2, (h + 1) * B // 2)
-        ctx = ChmcContext("sir", 1.0, 200, 14, wl.y[:, 0], sigma=1.0, num_chains=B // 2)
+    n_ok, Bs = 0, B // shards
+    for h in range(shards):
+        sl = slice(h * Bs, (h + 1) * Bs)
+        ctx = ChmcContext("sir", 1.0, 200, 14, wl.y[:, 0], sigma=1.0, num_chains=Bs)
         part = run(ctx, sl)
         ctx.close()
+        assert part[3] == 3
         for ra, rb in zip(whole[0], part[0]):
             for k in ra:
-                np.testing.assert_array_equal(ra[k][sl], rb[k], err_msg=f"{k} half {h}")
+                np.testing.assert_array_equal(ra[k][sl], rb[k], err_msg=f"{k} shard {h}")
         np.testing.assert_array_equal(whole[1][sl], part[1])
         np.testing.assert_array_equal(whole[2][sl], part[2])
         n_ok += int((part[0][-1]["status"] == 0).sum())
