@@ -620,7 +620,7 @@ __global__ void __launch_bounds__(64 * NW)
     wg_phase_sync();
     const int c5 = opaque_u(c);
     CHMC_TPROF(4);
-    for (int m = wv; m < sy.NOBS; m += NW) gld_fwd_ivl_body<M, RM>(sy, sl, w, 1, c5 * sy.NOBS + m);
+    for (int m = wv; m < sy.NOBS; m += NW) gld_fwd_ivl_body<M, RM, false>(sy, sl, w, 1, c5 * sy.NOBS + m);
     wg_phase_sync();
     const int c6 = opaque_u(c);
     CHMC_TPROF(5);

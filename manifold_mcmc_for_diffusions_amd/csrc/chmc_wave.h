@@ -3412,7 +3412,9 @@ __device__ inline bool gld_ivl_ids(const Sys& sy, const Work& w, int wid, int& c
   return w.ok[c] != 0 && j < sy.blk[b].nobs;
 }
 
-template <class M, int RM>
+// (UNTRACKED: the Qx stores are issued outside the compiler's vmcnt model, st_async.  The per-chain kernels pass false: they
+// contain generic-address (flat) accesses to LDS, beside which untracked stores are not allowed -- tools/check_scan_isa.py.)
+template <class M, int RM, bool UNTRACKED = true>
 __device__ __forceinline__ void gld_fwd_ivl_body(const Sys& sy, const Slots& sl, const Work& w, int which, int wid) {
   constexpr int X = M::X, V = M::V, Z = M::Z;
   constexpr int NC = CHMC_GCQ_N(X, Z);
@@ -3503,7 +3505,10 @@ __device__ __forceinline__ void gld_fwd_ivl_body(const Sys& sy, const Slots& sl,
         }
       if (valid) {
 #pragma unroll
-        for (int i = 0; i < X * X; ++i) st_async(Xd + (size_t)i * TS + s, xs[i]);
+        for (int i = 0; i < X * X; ++i) {
+          if constexpr (UNTRACKED) st_async(Xd + (size_t)i * TS + s, xs[i]);
+          else Xd[(size_t)i * TS + s] = xs[i];
+        }
       }
     }
     {
