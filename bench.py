@@ -503,8 +503,12 @@ def main():
                 tj = json.load(open(tf))
                 key = config_key(a.config, S, B)
                 sect = tj.get("configs", {}).get(key)
+                switches = sorted(k for k in os.environ if k.startswith("CHMC_") and k not in (
+                    "CHMC_BENCH_DEVICE", "CHMC_BENCH_VERBOSE", "CHMC_HIP_LIBRARY", "CHMC_DIST_BACKEND"))
                 if tj.get("_lib_sha256") != lib_sha256():
                     traffic_note = "profiles/traffic.json is from another build of the library: not quoted"
+                elif switches:  # (the counters were taken with the default kernel choices)
+                    traffic_note = f"environment switches {switches} select other kernels than the profiled defaults: not quoted"
                 elif wl.solver["newton"] is False or gaussian or sect is None:
                     traffic_note = f"profiles/traffic.json holds no counters for this workload ({key}): not quoted"
                 else:
