@@ -205,8 +205,9 @@ int chmc_switch_partition(chmc_ctx* ctx);
  *   CHMC_HALVES=2           two overlapped half-batches per step
  *   read at every call:
  *   CHMC_NO_FWD_SCAN=1      generic functor instead of the hand-scheduled forward scan
- *   CHMC_RETRACT_KERNEL=0/1 one 16-row block per chain: batched launches / one workgroup per chain (default: per chain up to two
- *                           chains per compute unit, batched beyond; the two give the same bits) */
+ *   CHMC_RETRACT_KERNEL=0/1/2  one 16-row block per chain: batched launches / one workgroup of 8 wavefronts per chain / of 4
+ *                           wavefronts (two chains per compute unit).  Default: 8 up to one chain per compute unit, 4 up to
+ *                           four, batched beyond; all three give the same bits */
 int chmc_constr(chmc_ctx* ctx, double* c);                                  /* :473-519, :1151-1155  [B][C] */
 /* :521-624, :1157-1161.  dc_du [B][C][U]; dc_dv [B][RM][NV] row-slot layout (slot i = row i of the block that
  * owns the column); dc/dn is sigma on observation rows (:601-608). */

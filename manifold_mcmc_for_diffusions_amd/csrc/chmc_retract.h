@@ -178,6 +178,9 @@ __device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, c
   const double* traj = (STATE ? pick(sl.traj, sp) : w.trajw) + (size_t)c * sy.TRJ + (size_t)bd.step0 * X;
   double* Jr = pick(sl.Jv, sp) + (size_t)c * RM * NV;      // (STATE: the v_0 columns are written)
   double* LFr = pick(sl.LF, sp) + cb * sy.NOBS * RM * X;   // (STATE: written)
+#ifdef CHMC_COMB_PROF
+  const long long tc0_ = wall_clock64();
+#endif
   // (a)
   for (int e = tid; e < nobs * NI; e += NT) Iv[e / NI][e % NI] = w.ivl[cb * sy.NOBS * NI + e];
   if constexpr (!STATE)
@@ -224,9 +227,10 @@ __device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, c
     if constexpr (STATE) LFr[e] = LamF[m][r];  // the frame of interval m (Slots::LF)
   }
   __syncthreads();
-  // (d) + (e)
-  if (tid < RM * RM) {
-    const int i = tid / RM, jj = tid - i * RM;
+  // (d) + (e)  (RM RM + RM Z work items: more than the 256 threads of the four-wavefront form)
+  for (int t = tid; t < RM * RM + RM * Z; t += NT) {
+  if (t < RM * RM) {
+    const int i = t / RM, jj = t - i * RM;
     double tt = 0.0;
     for (int m = nobs - 1; m >= 0; --m) {
 #pragma unroll
@@ -247,10 +251,10 @@ __device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, c
       if (sy.noisy && i < bd.ny) tt += sg_ * sigma_at(sy, pick(sl.q, sp) + (size_t)c * sy.Q);
       if (i >= bd.nrows) tt = 1.0;
     }
-    Dl[tid] = tt;
-    if constexpr (STATE) w.Dw[cb * RM * RM + tid] = tt;
-  } else if (tid < RM * RM + RM * Z) {
-    const int e = tid - RM * RM;
+    Dl[t] = tt;
+    if constexpr (STATE) w.Dw[cb * RM * RM + t] = tt;
+  } else {
+    const int e = t - RM * RM;
     const int i = e / Z, mz = e - i * Z;
     double tt = 0.0;
     for (int m = nobs - 1; m >= 0; --m) {
@@ -270,7 +274,9 @@ __device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, c
     zl[e] = tt;
     if constexpr (STATE) w.zbP[cb * RM * Z + e] = tt;
   }
+  }
   __syncthreads();
+  static_assert(RM * U <= NT && NT >= 64, "one thread per dc/du entry");
   if (tid < RM * U) {  // dc/du rows of the iterate through generate_z'(u)
     double G[Z * Z];
     M::gz_jac(q, G);
@@ -290,11 +296,18 @@ __device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, c
     if constexpr (STATE) pick(sl.JuP, sp)[cb * RM * U + tid] = tt;
   }
   __syncthreads();
+#ifdef CHMC_COMB_PROF  // (diagnostic: the combine of a Newton iteration, steps (a)-(e) | (f), 10 ns ticks in work.nfallback[54 | 55])
+  long long tc1_ = 0;
+  if (!STATE && tid == 0) tc1_ = wall_clock64(), atomicAdd(w.nfallback + 54, (int)(tc1_ - tc0_));
+#endif
   // (f)
   if (tid < 64) {
     if constexpr (STATE) state_factor16<M, RM>(sy, sl, w, prev, c, tid < 16, Dl, JuS, &Ys[0][0]);  // (Ys is free: L goes there)
-    else newton_factor16<M, RM, true, true>(sy, sl, w, prev, qsel, c, 0, tid < 16, Dl, JuS);
+    else newton_factor16<M, RM, true, true>(sy, sl, w, prev, qsel, c, 0, tid < 16, Dl, JuS, &LFp[0][0]);  // (mu_F from the LDS copy of the frames)
   }
+#ifdef CHMC_COMB_PROF
+  if (!STATE && tid == 0) atomicAdd(w.nfallback + 55, (int)(wall_clock64() - tc1_));
+#endif
 }
 
 // J p and J pg (k_jw_pb<.., TWO>) of the chain's block by the whole workgroup: the per-interval sums y_m = sum_s PB[s] w_s go to
@@ -367,6 +380,157 @@ __device__ __forceinline__ void jw_pb_wg(const Sys& sy, const Slots& sl, const W
     }
     w.cpad[cb * RM + i] = a;
     w.cpad2[cb * RM + i] = a2;
+  }
+}
+
+// gld_ivl_prologue_body (chmc_wave.h) for the chain's one block by the whole workgroup.  The wavefront form walks the
+// observation intervals one after the other with global loads and three wavefront barriers per interval (83 us per step of
+// a boarding-school chain, measured) although only the row tangents xd(t_m) form a recursion: here M LF[m] and the interval
+// matrices of EVERY interval are staged in LDS by all threads, 48 lanes run the recursion from LDS, and C1 / C2 / Q0 / the
+// terminal tangents of every interval follow in parallel.  Every entry is the same sum in the same order as in the wavefront
+// form (the batched path keeps k_gld_ivl_prologue: same bits).
+template <class M, int RM, int NW>
+__device__ __forceinline__ void gld_ivl_prologue_wg(const Sys& sy, const Slots& sl, const Work& w, int which, int c,
+                                                    const BlockDesc& bd, double* Mb /* LDS, RM x RM */) {
+  constexpr int X = M::X, Z = M::Z, V0 = M::V0, NT = 64 * NW;
+  constexpr int NI = CHMC_IVL_N(X, Z), NC = CHMC_GCQ_N(X, Z), MO = RM;
+  static_assert(RM * X <= 64, "the row tangents live in one wavefront");
+  __shared__ double zd[RM * Z], MLFa[MO][RM * X], Iva[MO][NI], xda[MO + 1][RM * X];
+  const int tid = threadIdx.x;
+  if (!w.ok[c]) return;  // (uniform)
+  const int s_ = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax;
+  const int NV = sy.NV, nobs = bd.nobs;
+  const double* Jv = pick(sl.Jv, s_) + (size_t)c * RM * NV;
+  const double* LFr = pick(sl.LF, s_) + cb * sy.NOBS * RM * X;
+  for (int i = tid; i < RM * RM; i += NT) Mb[i] = w.gMb[cb * RM * RM + i];
+  for (int i = tid; i < RM * Z; i += NT) zd[i] = w.gzd[cb * RM * Z + i];
+  for (int e = tid; e < nobs * NI; e += NT) Iva[e / NI][e % NI] = w.ivl[cb * sy.NOBS * NI + e];
+  __syncthreads();
+  for (int e = tid; e < nobs * RM * X; e += NT) {  // M LF[j] of every interval
+    const int j = e / (RM * X), l = e - j * RM * X;
+    const int i = l / X, a = l - i * X;
+    double t = 0.0;
+    for (int jj = 0; jj < RM; ++jj) t += Mb[i * RM + jj] * LFr[((size_t)j * RM + jj) * X + a];
+    MLFa[j][l] = t;
+  }
+  if (tid < RM * X) {  // the row tangents at the block's start
+    const int lane = tid;
+    const int i = lane / X, a = lane - i * X;
+    double t = 0.0;
+    if (bd.first) {
+      double dz[X * Z], dv0[X * V0];
+      M::gx0_jac(dz, dv0);
+      for (int mz = 0; mz < Z; ++mz) {
+        double dzs = 0.0;
+#pragma unroll
+        for (int e2 = 0; e2 < X * Z; ++e2) dzs = e2 == a * Z + mz ? dz[e2] : dzs;
+        t += dzs * zd[i * Z + mz];
+      }
+      for (int d = 0; d < V0; ++d) {
+        double wv = 0.0, dvs = 0.0;
+        for (int jj = 0; jj < RM; ++jj) wv += Mb[i * RM + jj] * Jv[(size_t)jj * NV + d];
+#pragma unroll
+        for (int e2 = 0; e2 < X * V0; ++e2) dvs = e2 == a * V0 + d ? dv0[e2] : dvs;
+        t += dvs * wv;
+      }
+    }
+    xda[0][lane] = t;
+  }
+  __syncthreads();
+  if (tid < 64) {  // the recursion over the intervals: xd(t_{j+1}) from xd(t_j), one wavefront, everything in LDS
+    const int lane = tid;
+    for (int j = 0; j < nobs; ++j) {
+      const double* xds = xda[j];
+      const double* MLFs = MLFa[j];
+      const double* Iv = Iva[j];
+      double nx = 0.0;
+      if (lane < RM * X) {
+        const int i = lane / X, a = lane - i * X;
+#pragma unroll
+        for (int d = 0; d < X; ++d) nx += Iv[X * X + X * Z + a * X + d] * xds[i * X + d] + Iv[a * X + d] * MLFs[i * X + d];
+        for (int mz = 0; mz < Z; ++mz) nx += Iv[X * X + a * Z + mz] * zd[i * Z + mz];
+        xda[j + 1][lane] = nx;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < nobs * X * X; e += NT) {  // C1 = LF^T M LF, Q0 = LF^T xd(t_j)
+    const int j = e / (X * X), lane = e - j * X * X;
+    const int a1 = lane / X, a2 = lane - a1 * X;
+    double c1 = 0.0, q0 = 0.0;
+    for (int i = 0; i < RM; ++i) {
+      const double lf = LFr[((size_t)j * RM + i) * X + a1];
+      c1 += lf * MLFa[j][i * X + a2];
+      q0 += lf * xda[j][i * X + a2];
+    }
+    double* Cj = w.gcq + (cb * sy.NOBS + j) * NC;
+    Cj[lane] = c1;
+    Cj[X * X + X * Z + lane] = q0;
+  }
+  for (int e = tid; e < nobs * X * Z; e += NT) {  // C2 = LF^T zd
+    const int j = e / (X * Z), lane = e - j * X * Z;
+    const int a1 = lane / Z, mz = lane - a1 * Z;
+    double c2 = 0.0;
+    for (int i = 0; i < RM; ++i) c2 += LFr[((size_t)j * RM + i) * X + a1] * zd[i * Z + mz];
+    w.gcq[(cb * sy.NOBS + j) * NC + X * X + lane] = c2;
+  }
+  for (int e = tid; e < nobs * X; e += NT) {  // terminal tangents of the observation rows: row j at the end of interval j
+    const int j = e / X, a = e - j * X;
+    if (j < bd.ny) w.gxdt[(cb * RM + j) * X + a] = xda[j + 1][j * X + a];
+  }
+}
+
+// KSymBlk (t_b = D_b^-1 v_b against the block's Cholesky factor, s_b = Ju_b^T t_b) for the chain's 16-row block by ONE
+// wavefront instead of one thread (whose 16 x 16 factor lived in scratch memory: two of them were most of the 93 us of a
+// step's "J p + core solves").  Bitwise cho_solve<16, 1>: the forward substitution runs column by column over the lanes (lane i
+// subtracts L_ik x_k for ascending k, the functor's order), the backward substitution -- whose sums over k > i ascend towards
+// values found last -- runs as the functor's own unrolled loop, the factor read from LDS; every lane holds the result.
+template <class M, int RM>
+__device__ __forceinline__ void sym_blk16_wave(const Sys& sy, const Slots& sl, const Work& w, int which, int c,
+                                               double* Ls /* LDS, RM x RM */) {
+  static_assert(RM == 16, "rows over 16 lanes");
+  constexpr int U = M::U;
+  const int lane = threadIdx.x & 63;
+  if (!w.ok[c]) return;  // (uniform)
+  const int s = sl.cur[c] ^ which;
+  const size_t cb = (size_t)c * sy.Kmax;
+  const double* fd = pick(sl.facD, s) + cb * RM * RM;
+  for (int i = lane; i < RM * RM; i += 64) Ls[i] = fd[i];
+  double t = lane < RM ? w.cpad[cb * RM + lane] : 0.0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int k = 0; k < RM; ++k) {
+    const double xk = readlane_d(t, k) / Ls[k * RM + k];
+    if (lane == k) t = xk;
+    if (lane > k && lane < RM) t -= Ls[lane * RM + k] * xk;
+  }
+  double x[RM];
+#pragma unroll
+  for (int k = 0; k < RM; ++k) x[k] = readlane_d(t, k);
+#pragma unroll
+  for (int i = RM - 1; i >= 0; --i) {
+    double tt = x[i];
+#pragma unroll
+    for (int k = 0; k < RM; ++k)
+      if (k > i) tt -= Ls[k * RM + i] * x[k];
+    x[i] = tt / Ls[i * RM + i];
+  }
+  if (lane < RM) {
+    double mine = 0.0;
+#pragma unroll
+    for (int k = 0; k < RM; ++k) mine = lane == k ? x[k] : mine;
+    w.tpad[cb * RM + lane] = mine;
+  }
+  if (lane < U) {
+    const double* ju = pick(sl.JuP, s) + cb * RM * U;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < RM; ++i) acc += ju[i * U + lane] * x[i];
+    w.sb[cb * U + lane] = acc;
   }
 }
 
@@ -501,7 +665,7 @@ __device__ __forceinline__ void retract_chain_body(const Sys& sy, const Slots& s
   }
 }
 template <class M, int RM, int NW>
-__global__ void __launch_bounds__(64 * NW)
+__global__ void __launch_bounds__(64 * NW, 2)  // (two wavefronts per SIMD: 256 registers, two 4-wavefront workgroups per CU)
     k_retract_chain(Sys sy, Slots sl, Work w, int prev, int qsel, double ctol, double ptol, double dtol, int max_iters,
                     int* iters_dst) {
   const int c = blockIdx.x;  // K == 1: the work order of the wave-per-block kernels is the identity
@@ -537,7 +701,7 @@ __device__ __forceinline__ void wave_sync() {  // the calling wavefront's own gl
 }
 
 template <class M, int RM, int NW>
-__global__ void __launch_bounds__(64 * NW)
+__global__ void __launch_bounds__(64 * NW, 2)
     k_traj_chain(Sys sy, Slots sl, Work w, const int* n_steps, int n_steps_all, double ctol, double ptol, double dtol,
                  int max_iters, double rev_tol, int* itf, int* itb, int* n_done) {
   constexpr int X = M::X, V = M::V, NT = 64 * NW;
@@ -546,6 +710,7 @@ __global__ void __launch_bounds__(64 * NW)
   const int tid = threadIdx.x, wv = tid >> 6;
   __shared__ int sOk;
   __shared__ unsigned long long sRev[NW];
+  __shared__ double wgL[RM * RM];  // a 16 x 16 matrix for whichever phase needs one (interval prologue, block solves)
   const BlockDesc bd = sy.blk[0];
   const int nst = n_steps ? n_steps[c] : n_steps_all;
   const int ncol = sy.T * sy.S + sy.V0 + (sy.noisy ? sy.T : 0);
@@ -569,9 +734,27 @@ __global__ void __launch_bounds__(64 * NW)
       tq_ = t1_;                                              \
     }                                                         \
   } while (0)
+#ifdef CHMC_COMB_PROF
+#define CHMC_TPROF2_ON 0
+#else
+#define CHMC_TPROF2_ON 1
+#endif
+// (wavefront 0's own timeline inside the state-evaluation phase: work.nfallback[54 | 55 | 63] = combine + Cholesky | chain core |
+// grad-log-det preparation, 10 ns ticks since the phase's last CHMC_TPROF; the phase's remainder is the interval prologue)
+#define CHMC_TPROF2(slot)                                                         \
+  do {                                                                            \
+    if (CHMC_TPROF2_ON && tid == 0) {                                                               \
+      const long long t1_ = wall_clock64();                                       \
+      atomicAdd(w.nfallback + (slot), (int)(t1_ - tq2_));                         \
+      tq2_ = t1_;                                                                 \
+    }                                                                             \
+  } while (0)
 #else
 #define CHMC_TPROF(slot) \
   do {                   \
+  } while (0)
+#define CHMC_TPROF2(slot) \
+  do {                    \
   } while (0)
 #endif
   for (int step = 0; step < nst; ++step) {
@@ -608,15 +791,22 @@ __global__ void __launch_bounds__(64 * NW)
     wg_phase_sync();
     const int c4 = opaque_u(c);
     CHMC_TPROF(3);
+#ifdef CHMC_RETRACT_PROF
+    long long tq2_ = wall_clock64();
+#endif
     newton_comb_wg<M, RM, NW, true>(sy, sl, w, 1, 0, c4, bd);  // ... and the block's Cholesky factor, E, C_b (16 lanes)
     if (wv == 0) {
       wave_sync();
+      CHMC_TPROF2(54);
       if (tid == 0) KStateChain<M>{sy, sl, w, 1}(c4);
       wave_sync();
+      CHMC_TPROF2(55);
       gld_prep_body<M, RM>(sy, sl, w, 1, c4, 1);
       wave_sync();
-      gld_ivl_prologue_body<M, RM>(sy, sl, w, 1, c4, 0);
+      CHMC_TPROF2(63);
     }
+    wg_phase_sync();
+    gld_ivl_prologue_wg<M, RM, NW>(sy, sl, w, 1, opaque_u(c), bd, wgL);
     wg_phase_sync();
     const int c5 = opaque_u(c);
     CHMC_TPROF(4);
@@ -649,11 +839,11 @@ __global__ void __launch_bounds__(64 * NW)
       Work w1 = w, w2 = w;
       w1.lampad = w.lampad2;
       w2.cpad = w.cpad2;
-      if (tid == 0) KSymBlk<M, RM>{sy, sl, w1, 1, 0}(c10);
+      sym_blk16_wave<M, RM>(sy, sl, w1, 1, c10, wgL);
       wave_sync();
       solve_chain_body<M, RM, 1, 1>(sy, sl, w1, 1, 0, 0, c10);
       wave_sync();
-      if (tid == 0) KSymBlk<M, RM>{sy, sl, w2, 1, 0}(c10);
+      sym_blk16_wave<M, RM>(sy, sl, w2, 1, c10, wgL);
       wave_sync();
       solve_chain_body<M, RM, 1, 1>(sy, sl, w2, 1, 0, 3, c10);
     }

@@ -1084,7 +1084,8 @@ __device__ __forceinline__ double row16_sum(double v) {  // sum over the 16 lane
 }
 template <class M, int RM, bool FUSE, bool ONE = false>
 __device__ __forceinline__ void newton_factor16(const Sys& sy, const Slots& sl, const Work& w, int prev, int qsel, int c, int b,
-                                                bool act, const double* Dsrc, const double* Jusrc) {
+                                                bool act, const double* Dsrc, const double* Jusrc,
+                                                const double* lf_copy = nullptr) {  // (the block's frames LF[m][i][x] in LDS)
   static_assert(RM == 16, "rows over 16 lanes");
   constexpr int U = M::U, NC = RM + 1 + U;  // augmented row: D row | c | dc/du row
   const int lane = threadIdx.x & 63, r = lane & 15;
@@ -1252,7 +1253,7 @@ __device__ __forceinline__ void newton_factor16(const Sys& sy, const Slots& sl, 
     __builtin_amdgcn_wave_barrier();
     if (act && w.muF) {  // mu_F[m] = sum_i lambda_i LF[m][i] of the previous point's interval frames (KMuF)
       const BlockDesc bd = sy.blk[b];
-      const double* lfb = pick(sl.LF, sp) + cb * sy.NOBS * RM * X;
+      const double* lfb = ONE ? lf_copy : pick(sl.LF, sp) + cb * sy.NOBS * RM * X;  // (ONE: the caller's LDS copy)
       double* mo = w.muF + cb * sy.NOBS * X;
       const double* ls = lamS[lane >> 4];
       for (int e = r; e < sy.NOBS * X; e += 16) {
@@ -5000,6 +5001,8 @@ __device__ __forceinline__ bool fwd_par_sweeps(const Sys& sy, const Work& w, con
       for (int k = 0; k < PRE; ++k)
         if (s0 + k < s1) one_step(vpre + k * V);
     } else {
+      // (measured, round 4: requesting the increments of step s + 1 before step s is integrated changes nothing -- 27.4 us of
+      // recursion per Newton iteration either way: the step's own dependent arithmetic is the latency, not its loads)
       for (int s = s0; s < s1; ++s) {
         double vv[V];
 #pragma unroll

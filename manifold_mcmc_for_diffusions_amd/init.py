@@ -101,12 +101,27 @@ def init_objective_and_grad_device(ctx, u_v_dev_ptr, grad_dev_ptr):
 
 
 def _adam_on_device(ctx, rng, adam_step_size, max_iters, max_init_tries, threshold, slow_progress_ratio, check_iter,
-                    max_num_tries, log):
+                    max_num_tries, log, max_parallel_tries=16, _calls=None):
     """The finder with (u_v, m, v) and the gradient resident in HBM: per Adam iteration TWO library calls -- objective +
     gradient + row statistics (scan, adjoint sweep, one [B, 3] read-back), then the Adam step (one kernel, one [B, 2]
-    upload); the [B, Q] arrays never cross PCIe.  Same restart rules as the host loop below."""
+    upload); the [B, Q] arrays never cross PCIe.  Same restart rules as the host loop below.
+
+    The B rows of the context are SLOTS: slot s starts as try 0 of chain s.  The reference's finder (:1741-1789) runs a
+    chain's tries one after the other and keeps the first that reaches the threshold; a batch would then iterate for its
+    unluckiest chain (boarding-school SIR with sigma = generate_σ_y(u), 1 024 chains: up to 14 tries of 100+ iterations)
+    with nearly every row idle.  Rows of finished chains are therefore handed to the chains still searching, which run their
+    next tries k+1, k+2, ... side by side; the chain's result is still its FIRST successful try in try order (a later try
+    that succeeds earlier waits, frozen, until every earlier one has failed), so each chain's answer is distributed as
+    with sequential tries, and `tries` counts as the reference does."""
     import torch
-    dev = _torch_device(ctx)
+    if _calls is None:                                     # the two library calls of an iteration, on device pointers
+        dev = _torch_device(ctx)
+        sync = lambda: torch.cuda.synchronize(dev)         # (the library enqueues on its own stream)
+        objective = lambda u_v, g: ctx.adam_objective_device(u_v.data_ptr(), g.data_ptr())
+        adam_update = lambda u_v, m, v, g, coef, b1, b2, eps: ctx.adam_update_device(
+            u_v.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), coef, b1, b2, eps)
+    else:                                                  # (CPU test of the slot bookkeeping: stand-ins on CPU tensors)
+        dev, sync, objective, adam_update = _calls
     B, Q, T = ctx.B, ctx.Q, ctx.T
     nuv = Q - T
     var_sigma = getattr(ctx, "variable_sigma", False)
@@ -114,49 +129,133 @@ def _adam_on_device(ctx, rng, adam_step_size, max_iters, max_init_tries, thresho
     u_v = torch.from_numpy(rng.standard_normal((B, nuv))).to(dev)
     m, v, g = torch.zeros_like(u_v), torch.zeros_like(u_v), torch.empty_like(u_v)
     t_adam = np.zeros(B)
-    done = np.zeros(B, dtype=bool)
-    tries = np.ones(B, dtype=np.int64)
     prev = np.full(B, np.inf)
     it_in_try = np.zeros(B, dtype=np.int64)
+    # slots: 0 = iterating, 1 = reached the threshold (frozen), 2 = free
+    slot_state = np.zeros(B, dtype=np.int64)
+    owner, tryno = np.arange(B), np.zeros(B, dtype=np.int64)
+    # chains: the tries handed out so far (try -> slot or -1 = failed), the first try not known to have failed, the winner
+    status = [{0: c} for c in range(B)]
+    kstar = np.zeros(B, dtype=np.int64)
+    next_try = np.ones(B, dtype=np.int64)
+    winner = np.full(B, -1, dtype=np.int64)
+    result = torch.zeros_like(u_v)                         # every chain's first successful try
+    n_running = np.ones(B, dtype=np.int64)
+    limit = max_num_tries * max_init_tries
     b1, b2, eps = 0.9, 0.999, 1e-8                         # jax.example_libraries.optimizers.adam defaults
+    ls_host = torch.empty(B, dtype=torch.float64)
+    if dev.type == "cuda":
+        ls_host = ls_host.pin_memory()
+    sync()                                                 # (the draws are on the device before the library reads them)
+
+    def release(c, s):
+        if slot_state[s] == 0:
+            n_running[c] -= 1
+        slot_state[s] = 2
+
+    def resolve(c):
+        """first try in try order that has not failed: the winner if it has reached the threshold.  Its point moves to the
+        result buffer and ALL the chain's slots become free"""
+        while status[c].get(int(kstar[c])) == -1:
+            kstar[c] += 1
+        s = status[c].get(int(kstar[c]))
+        if s is not None and slot_state[s] == 1:
+            winner[c] = s
+            result[c] = u_v[s]
+            for k, s2 in status[c].items():
+                if s2 >= 0 and slot_state[s2] != 2 and owner[s2] == c and tryno[s2] == k:
+                    release(c, s2)
+
     for _ in range(max_iters * max_num_tries):
-        torch.cuda.synchronize(dev)                        # (the library enqueues on its own stream)
-        st = ctx.adam_objective_device(u_v.data_ptr(), g.data_ptr())   # objective, |u_v|^2, gradient finite: one read-back
+        # log sigma: a number, or generate_sigma(u) = exp(u[dim_z]) per slot: B doubles read back per iteration, the copy
+        # (torch's stream) runs beside the library's scan and adjoint sweep (its own stream; library calls return synchronised)
+        if var_sigma:
+            ls_host.copy_(u_v[:, isig], non_blocking=True)
+        st = objective(u_v, g)                             # objective, |u_v|^2, gradient finite: one read-back
         val, sq, gfin = st[:, 0], st[:, 1], st[:, 2] != 0.0
-        # log sigma: a number, or generate_sigma(u) = exp(u[dim_z]) per chain (B doubles read back per iteration)
-        log_sigma = u_v[:, isig].cpu().numpy() if var_sigma else np.log(float(ctx.sigma))
-        msq = 2.0 * (val - T * log_sigma - 0.5 * sq) / T   # mean squared residual
-        newly = ~done & np.isfinite(msq) & (msq < threshold)
-        done |= newly
-        if done.all():
-            break
-        stalled = (it_in_try % check_iter == 0) & (it_in_try > 0) & (it_in_try < max_iters // 2) & (
-            msq / prev > slow_progress_ratio)
-        restart = ~done & (~np.isfinite(msq) | ~gfin | stalled | (it_in_try >= max_iters))
-        upd = (it_in_try % check_iter == 0) & ~restart
+        if var_sigma:
+            sync()
+            log_sigma = ls_host.numpy()
+        else:
+            log_sigma = np.log(float(ctx.sigma))
+        with np.errstate(invalid="ignore", over="ignore"):
+            msq = 2.0 * (val - T * log_sigma - 0.5 * sq) / T   # mean squared residual
+            running = slot_state == 0
+            reached = running & np.isfinite(msq) & (msq < threshold)
+            stalled = (it_in_try % check_iter == 0) & (it_in_try > 0) & (it_in_try < max_iters // 2) & (
+                msq / prev > slow_progress_ratio)
+        failed = running & ~reached & (~np.isfinite(msq) | ~gfin | stalled | (it_in_try >= max_iters))
+        upd = (it_in_try % check_iter == 0) & running & ~failed
         prev = np.where(upd, msq, prev)
-        if restart.any():
-            if (tries[restart] >= max_num_tries * max_init_tries).any():
-                raise RuntimeError(f"Did not find valid state in {max_num_tries} tries.")
-            idx = torch.from_numpy(np.flatnonzero(restart)).to(dev)
-            u_v[idx] = torch.from_numpy(rng.standard_normal((int(restart.sum()), nuv))).to(dev)
+        touched = set()
+        for s in np.flatnonzero(reached):
+            slot_state[s] = 1
+            n_running[owner[s]] -= 1
+            touched.add(int(owner[s]))
+        for s in np.flatnonzero(failed):
+            c = int(owner[s])
+            status[c][int(tryno[s])] = -1
+            release(c, s)
+            touched.add(c)
+        for c in touched:
+            if winner[c] < 0:
+                resolve(c)
+        if (winner >= 0).all():
+            break
+        # hand the free slots to the chains still searching (slots only change hands when something happened): one more
+        # try per chain and turn, fewest running tries first
+        fresh = []
+        if touched:
+            free = list(np.flatnonzero(slot_state == 2))
+            searching = [int(c) for c in np.flatnonzero(winner < 0)]
+            while free:
+                cand = [c for c in searching if n_running[c] < max_parallel_tries and next_try[c] < limit]
+                if not cand:
+                    break
+                cand.sort(key=lambda c: n_running[c])
+                for c in cand[:len(free)]:
+                    s = int(free.pop())
+                    owner[s], tryno[s], slot_state[s] = c, next_try[c], 0
+                    status[c][int(next_try[c])] = s
+                    next_try[c] += 1
+                    n_running[c] += 1
+                    fresh.append(s)
+            for c in touched:
+                if winner[c] < 0 and n_running[c] == 0 and not any(
+                        s2 >= 0 and slot_state[s2] == 1 and owner[s2] == c for s2 in status[c].values()):
+                    raise RuntimeError(f"Did not find valid state in {max_num_tries} tries.")
+        idle = np.flatnonzero((slot_state == 2) & (reached | failed | np.isin(owner, list(touched)))) if touched else []
+        if len(idle):                                      # a slot left idle holds a harmless point (a failed try may be NaN)
+            idx = torch.from_numpy(np.asarray(idle)).to(dev)
+            u_v[idx], m[idx], v[idx], g[idx] = 0.0, 0.0, 0.0, 0.0
+        if fresh:
+            fr = np.asarray(fresh)
+            idx = torch.from_numpy(fr).to(dev)
+            u_v[idx] = torch.from_numpy(rng.standard_normal((len(fresh), nuv))).to(dev)
             m[idx], v[idx] = 0.0, 0.0
-            g[idx] = 0.0                                   # (a restarted chain's moments start from zero at its next gradient)
-            t_adam[restart], it_in_try[restart], prev[restart] = 0.0, 0, np.inf
-            tries[restart] += 1
-            torch.cuda.synchronize(dev)
-        step = ~done & ~restart
+            g[idx] = 0.0                                   # (a fresh try's moments start from zero at its next gradient)
+            t_adam[fr], it_in_try[fr], prev[fr] = 0.0, 0, np.inf
+        if fresh or len(idle):
+            sync()
+        step = slot_state == 0
+        if fresh:
+            step[np.asarray(fresh)] = False
         t_adam[step] += 1
-        # Adam moments in place for every chain (a finished chain's moments are never used again, a restarted chain's were
+        # Adam moments in place for every slot (a frozen or free slot's moments are never used again, a fresh try's were
         # zeroed above and its gradient dropped); only the parameter update is masked: one library kernel
         tt = np.maximum(t_adam, 1.0)
         coef = np.stack([1.0 / (1 - b2 ** tt), np.where(step, adam_step_size / (1 - b1 ** tt), 0.0)], 1)
-        ctx.adam_update_device(u_v.data_ptr(), m.data_ptr(), v.data_ptr(), g.data_ptr(), coef, b1, b2, eps)
+        adam_update(u_v, m, v, g, coef, b1, b2, eps)
         it_in_try[step] += 1
         if log is not None and int(it_in_try.max()) % check_iter == 0:
-            log(f"  adam (device): {int(done.sum())} of {B} chains below the threshold, median mean r^2 {np.median(msq):.3g}")
+            log(f"  adam (device): {int((winner >= 0).sum())} of {B} chains below the threshold, "
+                f"{int((slot_state == 0).sum())} tries running")
     else:
         raise RuntimeError("Did not find valid states within the iteration budget.")
+    tries = kstar + 1
+    u_v = result
+    if _calls is not None:
+        return u_v, tries, status
     # n := residuals puts the point on the manifold (:1767-1775): one state evaluation at [u_v, 0] gives obs_func(x_t) - y_t
     q = np.concatenate([u_v.cpu().numpy(), np.zeros((B, T))], 1)
     xo0 = np.zeros((B, T, ctx.X))

@@ -185,3 +185,60 @@ def test_static_sampler_with_metric_adaptation(emu_lib):  # noqa: F811
     p[:, :4] = p[:, :4] @ np.linalg.inv(ctx.M_0).T
     assert np.abs(ctx.lmult_by_jacob_constr(p)).max() < 1e-8 * np.abs(p).max()
     ctx.close()
+
+
+def test_adam_finder_parallel_tries_keep_the_first_successful_try_in_try_order():
+    """Slot bookkeeping of the device-resident initial-state finder (init._adam_on_device) with stand-ins for its two library
+    calls: rows of finished chains run the later tries of the chains still searching side by side, but a chain's result must
+    be its FIRST successful try in try order, as the reference's sequential tries give (sde/mici_extensions.py:1741-1789).
+    Landscape: a try whose draw has u[0] > 0 never gets below the threshold (stalls, or is NaN at once for u[0] > 1.5)."""
+    import torch
+    from types import SimpleNamespace
+    from manifold_mcmc_for_diffusions_amd import init
+    B, T, nuv = 48, 6, 12
+    ctx = SimpleNamespace(B=B, Q=nuv + T, T=T, U=3, sigma=1.0, variable_sigma=False)
+    n_calls = [0]
+
+    def objective(u_v, g):
+        n_calls[0] += 1
+        u = u_v.numpy()
+        bad = u[:, 0] > 0
+        h = 10.0 * np.mean(u[:, 1:] ** 2, 1) + np.where(bad, 2.0, 0.0)
+        val = 0.5 * T * h + 0.5 * np.sum(u ** 2, 1)
+        val = np.where(u[:, 0] > 1.5, np.nan, val)
+        gr = u.copy()
+        gr[:, 0] = 0.0  # (the draw's fate is fixed: u[0] never moves)
+        gr[:, 1:] += 0.5 * T * 20.0 * u[:, 1:] / (nuv - 1)
+        g.copy_(torch.from_numpy(gr))
+        return np.stack([val, np.sum(u ** 2, 1), np.ones(B)], 1)
+
+    def adam_update(u_v, m, v, g, coef, b1, b2, eps):
+        c = torch.from_numpy(coef)
+        m.mul_(b1).add_((1 - b1) * g)
+        v.mul_(b2).add_((1 - b2) * g * g)
+        u_v.sub_(c[:, 1:2] * m / (torch.sqrt(v * c[:, 0:1]) + eps))
+
+    class Rng:  # records the draws in order
+        def __init__(self):
+            self.r, self.rows = np.random.default_rng(5), []
+        def standard_normal(self, shape):
+            x = self.r.standard_normal(shape)
+            self.rows.append(x.copy())
+            return x
+
+    rng = Rng()
+    u_v, tries, status = init._adam_on_device(ctx, rng, 0.1, 1000, 100, 1.0, 0.8, 100, 10, None, max_parallel_tries=4,
+                                              _calls=(torch.device("cpu"), lambda: None, objective, adam_update))
+    u = u_v.numpy()
+    first = rng.rows[0]
+    assert (u[:, 0] <= 0).all() and (10.0 * np.mean(u[:, 1:] ** 2, 1) < 1.0).all()
+    ok0 = first[:, 0] <= 0
+    assert (tries[ok0] == 1).all() and (tries[~ok0] >= 2).all() and tries.max() >= 3
+    # a chain that kept its first try returns the descendant of ITS draw
+    assert (u[ok0, 0] == first[ok0, 0]).all()
+    for c in range(B):
+        assert all(status[c][k] == -1 for k in range(int(tries[c]) - 1)) and status[c][int(tries[c]) - 1] >= 0
+    # the later tries ran side by side: far fewer iterations than the sum over the unluckiest chain's tries
+    # (a stalling try is given up at its second check, after 200 iterations: sequential tries would need 200 per failed try of
+    # the unluckiest chain, about 1 000 iterations here)
+    assert tries.max() >= 5 and n_calls[0] < 500, (n_calls[0], tries.max())

@@ -58,6 +58,11 @@ if xt.sum() > 0:
     for nm, t in zip(names, xt):
         print(f"    {nm:40s} {t/steps:8.1f}  ({100*t/xt.sum():.0f} %)")
     print(f"    {'total':40s} {xt.sum()/steps:8.1f}")
+if os.environ.get("CHMC_COMB_PROF_BUILD"):
+    print(f"    combine of a Newton iteration: steps (a)-(e) {d[54]*0.01/n_it:.1f} us, (f) LU / core / multipliers / mu_F {d[55]*0.01/n_it:.1f} us")
+elif d[54] + d[55] + d[63] > 0:
+    print(f"    inside 'combine / Cholesky / prep / prologue' (wavefront 0): combine + Cholesky {d[54]*0.01/steps:.1f}, chain core "
+          f"{d[55]*0.01/steps:.1f}, grad-log-det preparation {d[63]*0.01/steps:.1f} us per chain-step; the rest is the interval prologue")
 ns = sweeps[:15] + sweeps[16:31] + sweeps[32:47]
 tot = ns.sum()
 print("sweeps to settle (histogram over scans, +1 final sweep each):", ns.tolist(), "mean", (ns * np.arange(1, 16)).sum() / max(tot, 1))
