@@ -101,12 +101,13 @@ OTHER_CONFIGS = [  # the other single-GPU BASELINE.json shapes, run as short chi
 
 def run_other_configs(a):
     """Short legs of the other single-GPU BASELINE shapes, each in a fresh child process (its own context; this process
-    keeps its own): 4 warm-up + 16 timed steps, no CPU baseline.  Returns {name: summary or {"error": ...}}."""
+    keeps its own): 16 warm-up + 32 timed steps (whole trajectories of 16: the single-block layouts run a trajectory as one
+    launch per chain), no CPU baseline.  Returns {name: summary or {"error": ...}}."""
     import subprocess
     out = {}
     for name, extra in OTHER_CONFIGS:
-        cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--steps", "16",
-               "--warmup", "4", "--repeats", "0"] + extra
+        cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu-baseline", "--no-other-configs", "--steps", "32",
+               "--warmup", "16", "--repeats", "0"] + extra
         t0 = time.perf_counter()
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)

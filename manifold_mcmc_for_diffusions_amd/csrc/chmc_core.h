@@ -298,17 +298,21 @@ CHMC_HD inline void lu_factor(double* a, int* piv) {  // partial pivoting, LAPAC
 }
 template <int N, int NR>
 CHMC_HD inline void lu_solve(const double* lu, const int* piv, double* b) {  // b [N][NR] in place
+  // (the row exchanges as selects on statically indexed entries: written as `if (t == p) swap`, hipcc turns the unrolled
+  // comparison chain back into b[p], a dynamic index that puts the whole right-hand side into scratch memory -- every entry of
+  // the substitutions below then goes through it: k_newton_fsm_wave, 360 scratch accesses per Newton iteration)
   CHMC_UNROLL
   for (int i = 0; i < N; ++i) {
-    int p = piv[i];
+    const int p = piv[i];
     CHMC_UNROLL
     for (int t = 0; t < N; ++t)
-      if (t > i && t == p) {
+      if (t > i) {
+        const bool sw = t == p;
         CHMC_UNROLL
         for (int c = 0; c < NR; ++c) {
-          double s = b[i * NR + c];
-          b[i * NR + c] = b[t * NR + c];
-          b[t * NR + c] = s;
+          const double s = b[i * NR + c], u = b[t * NR + c];
+          b[i * NR + c] = sw ? u : s;
+          b[t * NR + c] = sw ? s : u;
         }
       }
   }

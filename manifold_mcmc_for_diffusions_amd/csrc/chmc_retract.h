@@ -190,11 +190,17 @@ __device__ __forceinline__ void newton_comb_wg(const Sys& sy, const Slots& sl, c
   // interval m (after the rows that start there have been injected), LamF[MO] = the rows at the block's start
   if (tid < RM) {
     const int i = tid;
-    double row[X];
+    double row[X], og[X];
 #pragma unroll
-    for (int a = 0; a < X; ++a) row[a] = 0.0;
+    for (int a = 0; a < X; ++a) row[a] = 0.0, og[a] = 0.0;
+    // (the observation row's gradient is fetched before the walk: inside it, the one thread's global load of interval m stalled
+    // the whole wavefront once per interval -- 14 round trips in sequence, two thirds of steps (a)-(e) of a Newton iteration)
+    if (i < bd.ny && i < nobs) M::obs_grad(traj + (size_t)(i + 1) * S * X, og);
     for (int m = nobs - 1; m >= 0; --m) {
-      if (m < bd.ny && i == m) M::obs_grad(traj + (size_t)(m + 1) * S * X, row);
+      if (m < bd.ny && i == m) {
+#pragma unroll
+        for (int a = 0; a < X; ++a) row[a] = og[a];
+      }
       if (m == nobs - 1 && !bd.last && i >= bd.ny && i < bd.ny + X) {
 #pragma unroll
         for (int a = 0; a < X; ++a) row[a] = (a == i - bd.ny) ? 1.0 : row[a];

@@ -206,20 +206,20 @@ def _adam_on_device(ctx, rng, adam_step_size, max_iters, max_init_tries, thresho
         # try per chain and turn, fewest running tries first
         fresh = []
         if touched:
-            free = list(np.flatnonzero(slot_state == 2))
-            searching = [int(c) for c in np.flatnonzero(winner < 0)]
-            while free:
-                cand = [c for c in searching if n_running[c] < max_parallel_tries and next_try[c] < limit]
-                if not cand:
+            free = np.flatnonzero(slot_state == 2)
+            searching = np.flatnonzero(winner < 0)
+            while free.size:
+                cand = searching[(n_running[searching] < max_parallel_tries) & (next_try[searching] < limit)]
+                if cand.size == 0:
                     break
-                cand.sort(key=lambda c: n_running[c])
-                for c in cand[:len(free)]:
-                    s = int(free.pop())
-                    owner[s], tryno[s], slot_state[s] = c, next_try[c], 0
-                    status[c][int(next_try[c])] = s
-                    next_try[c] += 1
-                    n_running[c] += 1
-                    fresh.append(s)
+                cand = cand[np.argsort(n_running[cand], kind="stable")][:free.size]
+                take, free = free[:cand.size], free[cand.size:]
+                owner[take], tryno[take], slot_state[take] = cand, next_try[cand], 0
+                for c, s_ in zip(cand.tolist(), take.tolist()):
+                    status[c][int(next_try[c])] = s_
+                next_try[cand] += 1
+                n_running[cand] += 1
+                fresh.extend(take.tolist())
             for c in touched:
                 if winner[c] < 0 and n_running[c] == 0 and not any(
                         s2 >= 0 and slot_state[s2] == 1 and owner[s2] == c for s2 in status[c].values()):

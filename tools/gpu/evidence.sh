@@ -1,7 +1,8 @@
 # Everything the round's report cites, for the library build in the tree (run as ONE gpurun call, <= 20 min):
 #   counter traffic of the four single-GPU workloads -> profiles/traffic.json (+ per-kernel means), default bench line with
 #   cpu baseline and other_configs, kernel statistics (rocprofv3 --kernel-trace --stats) of the headline and of SIR, SIR
-#   bench lines (256 / 1024 chains, lock-step A/B), phase breakdown of the per-chain kernels.     usage: evidence.sh <tag>
+#   bench lines (256 / 512 / 1024 chains; 8 / 4 wavefronts per chain and batched launches forced), phase breakdown of the
+#   per-chain kernels, Adam finder timings.     usage: evidence.sh <tag>
 export TMPDIR=/tmp
 R=$PWD
 TAG=${1:-r04}
@@ -13,12 +14,17 @@ cp $R/profiles/traffic.json $R/profiles/${TAG}_pmc_*_by_kernel.csv $P/
 timeout -k 10 500 python bench.py > $O/bench_default.json 2> $O/bench_default.err || tail -5 $O/bench_default.err
 cp $O/bench_default.json $P/${TAG}_bench_default.json
 for cfg in sir fhn_noiseless; do
-  timeout -k 10 300 python bench.py --config $cfg --no-other-configs > $O/bench_$cfg.json 2> $O/e.log || tail -5 $O/e.log
+  WU=4; if [ $cfg = sir ]; then WU=16; fi   # (SIR: the timed region starts at a trajectory boundary: one launch per trajectory)
+  timeout -k 10 300 python bench.py --config $cfg --warmup $WU --no-other-configs > $O/bench_$cfg.json 2> $O/e.log || tail -5 $O/e.log
   cp $O/bench_$cfg.json $P/${TAG}_bench_$cfg.json
 done
-timeout -k 10 300 python bench.py --config sir --chains-per-gpu 1024 --no-cpu-baseline --no-other-configs > $P/${TAG}_bench_sir_1024.json 2> $O/e.log || tail -5 $O/e.log
-CHMC_RETRACT_KERNEL=0 timeout -k 10 300 python bench.py --config sir --no-cpu-baseline --no-other-configs > $P/${TAG}_bench_sir_lockstep_rounds.json 2> $O/e.log || tail -5 $O/e.log
-CHMC_RETRACT_KERNEL=0 timeout -k 10 300 python bench.py --config sir --chains-per-gpu 1024 --no-cpu-baseline --no-other-configs > $P/${TAG}_bench_sir_1024_lockstep_rounds.json 2> $O/e.log || tail -5 $O/e.log
+timeout -k 10 300 python bench.py --config sir --warmup 16 --chains-per-gpu 1024 --no-cpu-baseline --no-other-configs > $P/${TAG}_bench_sir_1024.json 2> $O/e.log || tail -5 $O/e.log
+CHMC_RETRACT_KERNEL=0 timeout -k 10 300 python bench.py --config sir --warmup 16 --no-cpu-baseline --no-other-configs > $P/${TAG}_bench_sir_lockstep_rounds.json 2> $O/e.log || tail -5 $O/e.log
+CHMC_RETRACT_KERNEL=0 timeout -k 10 300 python bench.py --config sir --warmup 16 --chains-per-gpu 1024 --no-cpu-baseline --no-other-configs > $P/${TAG}_bench_sir_1024_lockstep_rounds.json 2> $O/e.log || tail -5 $O/e.log
+timeout -k 10 300 python bench.py --config sir --warmup 16 --chains-per-gpu 512 --no-cpu-baseline --no-other-configs > $P/${TAG}_bench_sir_512.json 2> $O/e.log || tail -5 $O/e.log
+for b in 256 512 1024; do for k in 1 2; do
+  CHMC_RETRACT_KERNEL=$k timeout -k 10 300 python bench.py --config sir --warmup 16 --chains-per-gpu $b --no-cpu-baseline --no-other-configs > $P/${TAG}_bench_sir_${b}_wavefronts_$((k == 1 ? 8 : 4)).json 2> $O/e.log || tail -5 $O/e.log
+done; done
 timeout -k 10 300 python bench.py --num-steps-per-obs 800 --chains-per-gpu 512 --no-cpu-baseline --no-other-configs > $P/${TAG}_bench_fhn_noisy_s800_512.json 2> $O/e.log || tail -5 $O/e.log
 timeout -k 10 300 python bench.py --solver quasi-newton --no-cpu-baseline --no-other-configs > $P/${TAG}_bench_fhn_quasi_newton.json 2> $O/e.log || tail -5 $O/e.log
 timeout -k 10 300 python bench.py --splitting gaussian --no-cpu-baseline --no-other-configs > $P/${TAG}_bench_fhn_gaussian.json 2> $O/e.log || tail -5 $O/e.log

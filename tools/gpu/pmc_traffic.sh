@@ -15,13 +15,15 @@ for key in $KEYS; do
     fhn_noisy_s800_b512) ARGS="--config fhn_noisy --num-steps-per-obs 800 --chains-per-gpu 512";;
     *) echo "unknown workload key $key"; exit 1;;
   esac
-  CMD="python3 $R/bench.py --no-cpu-baseline --no-other-configs --repeats 0 --steps 4 --warmup 2 $ARGS"
+  SW="--steps 4 --warmup 2"
+  if [ $key = sir ]; then SW="--steps 16 --warmup 16"; fi  # (whole trajectories: one launch of k_traj_chain each)
+  CMD="python3 $R/bench.py --no-cpu-baseline --no-other-configs --repeats 0 $SW $ARGS"
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf $O/$key.$ctr
     (cd /tmp && timeout -k 10 400 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/$key.$ctr -- $CMD > $O/$key.$ctr.log 2>&1) || { echo "pmc pass $key $ctr failed"; tail -5 $O/$key.$ctr.log; exit 1; }
   done
   F=$(find $O/$key.FETCH_SIZE -name "*counter_collection.csv"); W=$(find $O/$key.WRITE_SIZE -name "*counter_collection.csv")
-  python tools/pmc_summary.py $F $W $R/profiles/traffic.json $key "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-other-configs --repeats 0 --steps 4 --warmup 2 $ARGS" > $O/$key.summary.txt 2>&1; tail -3 $O/$key.summary.txt
+  python tools/pmc_summary.py $F $W $R/profiles/traffic.json $key "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline --no-other-configs --repeats 0 $SW $ARGS" > $O/$key.summary.txt 2>&1; tail -3 $O/$key.summary.txt
   python - $F $W $R/profiles/${TAG}_pmc_${key}_by_kernel.csv <<'PY'
 import sys, pandas as pd
 rows = []

@@ -45,6 +45,14 @@ CLASS_OF = [  # substring of the kernel name -> profiling class of include/chmc.
 def per_class(path, counter):
     df = pd.read_csv(path)
     df = df[df["Counter_Name"] == counter]
+    # k_traj_chain (single-block layouts) walks a whole trajectory per launch: the burn-in of bench.py launches it for ONE step
+    # at a time, the warm-up and the timed region for traj_len steps.  Only the last two launches (warm-up and timed
+    # region of `--steps 16 --warmup 16`) have the shape of the launches bench.py times.
+    tr = df[df["Kernel_Name"].str.contains("k_traj_chain")]
+    if len(tr) > 2:
+        order = "Dispatch_Id" if "Dispatch_Id" in tr.columns else None
+        tr = tr.sort_values(order) if order else tr
+        df = df.drop(tr.index[:-2])
     out = {}
     for _, r in df.iterrows():
         for sub, cls in CLASS_OF:
@@ -86,7 +94,8 @@ def main():
     if res.get("_lib_sha256") != sha or "configs" not in res:
         res = {"_method": "bytes per launch = (factor * FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the launches of the "
                           "class; factor = calibrated bytes-per-FETCH_SIZE of the class's access pattern (`_fetch_factor`); "
-                          "two separate rocprofv3 --pmc passes of `bench.py --steps 4 --warmup 2` per workload",
+                          "two separate rocprofv3 --pmc passes of `bench.py --steps 4 --warmup 2` per workload (single-block layouts: `--steps 16 "
+                          "--warmup 16`, whole trajectories, and only the last two launches of k_traj_chain count)",
                "_fetch_factor_source": fac_src, "_lib_sha256": sha, "configs": {}}
     sect = {"_fetch_factor": {}}
     sect["_command"] = sys.argv[5] if len(sys.argv) > 5 else "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 4 --warmup 2"
