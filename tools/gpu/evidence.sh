@@ -34,7 +34,6 @@ cp $(find $O/prof -name "*kernel_stats.csv") $P/${TAG}_kernel_stats.csv; rm -rf 
 cp $(find $O/prof_sir -name "*kernel_stats.csv") $P/${TAG}_kernel_stats_sir.csv; rm -rf $O/prof_sir
 if [ -f $R/build/libchmc_prof.so ]; then
   CHMC_HIP_LIBRARY=$R/build/libchmc_prof.so timeout -k 10 300 python tools/retract_prof.py 256 2 > $P/${TAG}_sir_phase_breakdown_256.txt 2>&1
-  CHMC_HIP_LIBRARY=$R/build/libchmc_prof.so timeout -k 10 300 python tools/retract_prof.py 1024 2 > $P/${TAG}_sir_phase_breakdown_1024.txt 2>&1
 fi
 python tools/adam_timing.py 1024 0 > $P/${TAG}_adam_init_1024.log 2>&1
 python tools/adam_timing.py 1024 0 variable > $P/${TAG}_adam_init_1024_variable_sigma.log 2>&1
