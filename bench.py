@@ -219,17 +219,18 @@ def cpu_baseline(wl, model, q, p, xo, part, dt, n_steps, solver, gaussian):
                       f"(oracle/c/chmc_oracle.c, gcc {flags}), one chain per host thread, {el:.1f} s"}
 
 
-def cpu_autodiff_baseline():
+def cpu_autodiff_baseline(T=100):
     """SURVEY.md 8(d) baseline (ii): the Python restatement with torch.func fp64 autodiff standing in for JAX (jacrev of
-    a scan, grad through jacrev), one chain, one core, configs[0]'s shape (FHN noisy, T = 100, S = 50).  Eager PyTorch
-    interprets every time step in Python, which jitted XLA does not: a lower bound on what the reference's CPU path does,
-    quoted for completeness and not comparable with the compiled figures."""
+    a scan, grad through jacrev), one chain, one core, configs[0]'s shape (FHN noisy, T = 100, S = 50; the default line runs a
+    bounded sample of it, T = 20 observations = 4 sub-sequences, about 20 s).  Eager PyTorch interprets every time step in
+    Python, which jitted XLA does not: a lower bound on what the reference's CPU path does, quoted for completeness and not
+    comparable with the compiled figures."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle.py import models as omodels, system as osys
     from helpers import make_case
     torch.set_num_threads(1)
-    case = make_case("fhn", 100, 50, 5, True, B=1, seed=1)
+    case = make_case("fhn", T, 50, 5, True, B=1, seed=1)
     sysm = osys.make_system(omodels.fhn, 0.2, 50, 5, case["y"][:, None], sigma=0.1)
     st = osys.ConditionedDiffusionHamiltonianState(case["q"][0], case["x_obs"][0], 0)
     st.mom = sysm.sample_momentum(st, np.random.default_rng(0))
@@ -240,8 +241,9 @@ def cpu_autodiff_baseline():
     integ.step(st)
     el = time.perf_counter() - t0
     return {"value": 1.0 / el, "unit": "steps/s", "cores": 1, "kind": "port",
-            "sample": f"1 chain x 1 leapfrog step, torch.func autodiff restatement (oracle/py), FHN noisy T=100 S=50 "
-                      f"(configs[0] shape, dim_q 10106), eager PyTorch on one core, {el:.0f} s"}
+            "sample": f"1 chain x 1 leapfrog step, torch.func autodiff restatement (oracle/py), FHN noisy T={T} S=50 "
+                      f"({'configs[0] shape' if T == 100 else 'configs[0] with ' + str(T) + ' of its 100 observations'}, dim_q "
+                      f"{case['q'].shape[1]}), eager PyTorch on one core, {el:.0f} s"}
 
 
 def _finite(o):
@@ -648,6 +650,8 @@ def main():
             out["config"]["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
             if a.cpu_autodiff_baseline:
                 out["cpu_baseline"]["autodiff_restatement_S50"] = cpu_autodiff_baseline()
+            elif a.config == "fhn_noisy" and not a.no_other_configs:  # (the default line: a bounded sample of baseline (ii))
+                out["cpu_baseline"]["autodiff_restatement_S50_T20"] = cpu_autodiff_baseline(20)
         if world == 1 and a.config == "fhn_noisy" and not a.no_other_configs and not emu and wl.solver["newton"] \
                 and not gaussian and B == 256 and S == 400:
             out["config"]["other_configs"] = run_other_configs(a)
