@@ -1416,7 +1416,7 @@ struct double2_ {
 // streaming 16-byte load (Jacobian rows are read once per sweep: keep them out of the caches' way)
 CHMC_HD inline double2_ ld2_stream(const double* p) {
   double2_ r;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CHMC_PLAIN_STREAM)
   r.x = __builtin_nontemporal_load(p);
   r.y = __builtin_nontemporal_load(p + 1);
 #else

@@ -26,7 +26,12 @@ namespace chmc {
 // plain read leaves the lines allocated in L2 / Infinity Cache and the next scan's streaming stores to the same
 // addresses then run at half speed (tools/ubench/fwd_latency.hip: 107 us vs 187 us per scan), so the readers use
 // the non-temporal hint as well.
+#ifdef CHMC_PLAIN_STREAM  // (A/B build: plain loads instead of the streaming hint on the once-per-sweep operands; measured in
+                          // round 4 at configs[1]: 47.8 k against 49.7 k steps/s, the forward scan 134 -> 150 us beside the fuller caches)
+__device__ inline double ld_stream(const double* p) { return *p; }
+#else
 __device__ inline double ld_stream(const double* p) { return __builtin_nontemporal_load(p); }
+#endif
 
 // Stores the compiler does not see.  With one of its own stores pending, hipcc (ROCm 7.2) waits for vmcnt(0) at the
 // next use of a prefetched value, i.e. for the store acknowledgement, every tile.  A store issued through inline asm
@@ -4483,6 +4488,8 @@ __device__ __forceinline__ void vm_wait(d2_t (&r)[12]) {
 // non-temporal hint every new line is allocated in L2 and the per-CU write path (not HBM) paces the helper wave
 // (tools/ubench/fwd_latency.hip: 70 -> 49 ns per step)
 __device__ __forceinline__ void vm_store16_nt(double* p, const d2_t& v) {
+  // (nt: measured again in round 4 with the alternating chain order -- plain stores would leave the trajectory in the caches
+  // for the interval sums that read it next: those get 1 % faster, the scan 2 % slower, the step 0.3 % slower)
   asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
 }
 // generate_x_obs_seq (:384-397) of every chain's CURRENT state by multiple shooting over the whole chain (one wavefront
