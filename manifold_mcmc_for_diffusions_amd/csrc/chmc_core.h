@@ -2157,6 +2157,39 @@ struct KKickFlowPg {
     stv2(pick(sl.p, s ^ 1) + i, pn, wide, two);
   }
 };
+// The closing A(dt/2) of the previous step of a trajectory and KKickFlowPg of the next one in ONE pass (chmc_leapfrog_steps,
+// lock-step path): p1 = p - h pg goes back to the state slot (the state a failing step leaves behind), the flow starts from
+// p1 - h pg.  Same operations in the same order as KKickPg followed by KKickFlowPg; two vector passes less per step.
+// (Not used with a block metric: its u-part reads all of p_u while other work items would be rewriting it.)
+struct KKick2FlowPg {
+  Sys sy;
+  Slots sl;
+  Work w;
+  double hfrac;
+  CHMC_HD bool active(int c) const { return w.ok[c] != 0; }
+  CHMC_FI CHMC_HD void operator()(int c, int col) const {  // row launch: components col, col + 1 of chain c
+    const int s = sl.cur[c];
+    const double h = hfrac * w.dt[c];
+    const size_t i = (size_t)c * sy.Q + col;
+    const bool two = col + 1 < sy.Q, wide = two && !(sy.Q & 1);
+    const double2_ q0 = ldv2(pick(sl.q, s) + i, wide, two), pp = ldv2(pick(sl.p, s) + i, wide, two);
+    const double2_ g = ldv2(pick(sl.pg, s) + i, wide, two);
+    double2_ p1, p0, qn, pn;
+    p1.x = pp.x - h * g.x, p1.y = pp.y - h * g.y;  // KKickPg of the step before
+    p0.x = p1.x - h * g.x, p0.y = p1.y - h * g.y;
+    if (sy.gaussian) {
+      const double sn = w.sdt[c], cs = w.cdt[c];
+      qn.x = q0.x * cs + sn * p0.x, qn.y = q0.y * cs + sn * p0.y;
+      pn.x = p0.x * cs - sn * q0.x, pn.y = p0.y * cs - sn * q0.y;
+    } else {
+      qn.x = q0.x + w.dt[c] * p0.x, qn.y = q0.y + w.dt[c] * p0.y;
+      pn = p0;
+    }
+    stv2(pick(sl.p, s) + i, p1, wide, two);
+    stv2(pick(sl.q, s ^ 1) + i, qn, wide, two);
+    stv2(pick(sl.p, s ^ 1) + i, pn, wide, two);
+  }
+};
 // reverse check distance max |q_back - q_start| (mici maximum_norm); column-max kernel, two components per work item
 struct KRevDiff {
   static constexpr bool kFinish = false;

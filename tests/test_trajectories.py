@@ -96,6 +96,13 @@ def test_trajectories_equal_repeated_steps(emu_lib, model, T, S, R, noisy, gauss
         assert r["status"][3] == -1 and r["n_done"][3] == 0 and r["n_done"][5] == 0 and r["status"][5] == 0
         assert r["status"][4] > 0 and r["n_done"][4] == 0
         assert (r["n_done"][[0, 1, 2, 6]] <= n_steps[[0, 1, 2, 6]]).all() and r["n_done"].sum() >= 6
+        # every chain the same number of steps (an integration transition): the lock-step path fuses the closing A(dt/2) of
+        # a step with the opening A(dt/2) + flow of the next (KKick2FlowPg); a chain that fails later keeps the kicked momentum
+        dts2 = dts.copy()
+        dts2[2] = 0.6  # (fails, if at all, after its first steps)
+        a, b = run_both(case, dts2, 4, active=active, part=part, newton=newton, **SOLVER)
+        assert_same(a, b)
+        assert a[0]["status"][4] > 0 and (a[0]["n_done"][[0, 1, 6]] >= 1).all()
 
 
 def test_unprojected_momenta(emu_lib):  # noqa: F811
@@ -179,6 +186,10 @@ def test_trajectories_equal_repeated_steps_hip(model, T, S, R, noisy, gaussian, 
         a, b = run_both(case, dts, n_steps, active=active, part=part, newton=newton, **SOLVER)
         assert_same(a, b)
         assert (a[0]["status"][[4, 20]] > 0).all() and a[0]["n_done"].sum() > B
+        # the same number of steps for every chain: the fused kicks of the lock-step path (KKick2FlowPg)
+        a, b = run_both(case, dts, 4, active=active, part=part, newton=newton, **SOLVER)
+        assert_same(a, b)
+        assert (a[0]["n_done"][a[0]["status"] == 0] == 4).all() and (a[0]["n_done"] == 4).sum() > B // 2
 
 
 @pytest.mark.gpu
