@@ -2117,6 +2117,17 @@ struct KMomFixInitPg {
     stv2(pick(sl.pg, s) + i, go, wide, two);
   }
 };
+// KMomFixInitPg for the columns outside the step part only -- u, v_0 and the observation-noise components: work item `col` of
+// the U + V0 + (Q - U - NV) edge columns -- when the step columns are corrected inside the J p pass (k_jw_pb<.., FIX>).
+// (U, V0, NV even: a pair never straddles the gap.)
+struct KMomFixEdges {
+  KMomFixInitPg f;
+  CHMC_HD bool active(int c) const { return f.active(c); }
+  CHMC_FI CHMC_HD void operator()(int c, int col) const {
+    const int head = f.sy.U + f.sy.V0;
+    f(c, col < head ? col : col - head + f.sy.U + f.sy.NV);
+  }
+};
 // KKickPg into the other slot followed by KFlow from there, in one pass (tangent momentum at the start of a step)
 struct KKickFlowPg {
   Sys sy;

@@ -2183,8 +2183,13 @@ __global__ void __launch_bounds__(256) k_jw_wave(Sys sy, Slots sl, Work w, int w
 // J w from the compact rows (Slots::PB / LF), same interface and result arrays as k_jw_wave: inside observation
 // interval m the rows are LF[m][i] . PB[s], so the pass accumulates the row-independent y_m = sum_s PB[s] w_s (X values
 // per lane) and applies the frame once per interval: X V doubles of rows per step instead of up to RM V.
-template <int RM, int X, int V, bool TWO>
+// FIX (with TWO, 16-byte pairs): the momentum correction and pg <- dh1_dpos of KMomFixInitPg for the step columns ride along --
+// the pass reads the two positions, the momentum and the gradient instead of p and pg, writes the corrected p and pg back
+// (same expressions, same streaming hints) and uses them: one read of p and pg less per step (the columns outside the step
+// part -- u, v_0, observation noise -- are corrected by KMomFixEdges before this launch, they are read below).
+template <int RM, int X, int V, bool TWO, bool FIX = false>
 __device__ __forceinline__ void jw_pb_body(const Sys& sy, const Slots& sl, const Work& w, int which, int vsel_, int wid) {
+  static_assert(!FIX || (TWO && V == 2), "the fused momentum correction works on 16-byte pairs of p and pg");
   const bool minv = (vsel_ & 256) != 0;
   const int vsel = vsel_ & 255;
   const int lane = threadIdx.x & 63;
@@ -2202,6 +2207,13 @@ __device__ __forceinline__ void jw_pb_body(const Sys& sy, const Slots& sl, const
   const double* wv = vct + sy.U + sy.V0 + (size_t)bd.step0 * V;
   const double* wv2 = vct2 + sy.U + sy.V0 + (size_t)bd.step0 * V;
   const bool wide = V == 2 && !((sy.Q | sy.U | sy.V0) & 1);
+  // (FIX: the step columns of the other operands of KMomFixInitPg, and p / pg as destinations)
+  const size_t voff = (size_t)c * sy.Q + sy.U + sy.V0 + (size_t)bd.step0 * V;
+  const double* fqp = FIX ? pick(sl.q, s ^ 1) + voff : nullptr;
+  const double* fqn = FIX ? pick(sl.q, s) + voff : nullptr;
+  const double* fgr = FIX ? pick(sl.grad, s) + voff : nullptr;
+  double* fp = FIX ? pick(sl.p, s) + voff : nullptr;
+  double* fpg = FIX ? pick(sl.pg, s) + voff : nullptr;
   double acc[RM], acc2[RM];
 #pragma unroll
   for (int i = 0; i < RM; ++i) acc[i] = 0.0, acc2[i] = 0.0;
@@ -2222,7 +2234,26 @@ __device__ __forceinline__ void jw_pb_body(const Sys& sy, const Slots& sl, const
 #pragma unroll
         for (int e = 0; e < X * V; ++e) pb[e] = ld_stream(src + e);
       }
-      if (wide) {
+      if constexpr (FIX) {  // KMomFixInitPg for this pair of columns
+        const size_t ko = (size_t)k * V;
+        const double2_ qp = ld2_stream(fqp + ko), qn = ld2_stream(fqn + ko);
+        const double2_ pn = ld2_stream(fp + ko), gr = ld2_stream(fgr + ko);
+        double sc;
+        double2_ flow, po, go;
+        if (sy.gaussian) {
+          sc = w.cdt[c] / w.sdt[c];
+          flow.x = (qp.x + w.sdt[c] * pn.x) / w.cdt[c], flow.y = (qp.y + w.sdt[c] * pn.y) / w.cdt[c];
+        } else {
+          sc = 1.0 / w.dt[c];
+          flow.x = qp.x + w.dt[c] * pn.x, flow.y = qp.y + w.dt[c] * pn.y;
+        }
+        po.x = pn.x - sc * (flow.x - qn.x), po.y = pn.y - sc * (flow.y - qn.y);
+        go.x = gr.x + (sy.gaussian ? 0.0 : qn.x), go.y = gr.y + (sy.gaussian ? 0.0 : qn.y);
+        stv2(fp + ko, po, true, true);
+        stv2(fpg + ko, go, true, true);
+        x[0] = po.x, x[V - 1] = po.y;
+        x2[0] = go.x, x2[V - 1] = go.y;
+      } else if (wide) {
         const double2_ v = *reinterpret_cast<const double2_*>(wv + (size_t)k * V);
         x[0] = v.x, x[V - 1] = v.y;
         if (TWO) {
@@ -2293,9 +2324,9 @@ __device__ __forceinline__ void jw_pb_body(const Sys& sy, const Slots& sl, const
     if (TWO) w.cpad2[cb * RM + i] = a2;
   }
 }
-template <int RM, int X, int V, bool TWO = false>
+template <int RM, int X, int V, bool TWO = false, bool FIX = false>
 __global__ void __launch_bounds__(256) k_jw_pb(Sys sy, Slots sl, Work w, int which, int vsel_) {
-  jw_pb_body<RM, X, V, TWO>(sy, sl, w, which, vsel_, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
+  jw_pb_body<RM, X, V, TWO, FIX>(sy, sl, w, which, vsel_, blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
 }
 
 

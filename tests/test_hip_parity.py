@@ -1054,3 +1054,45 @@ def test_sixteen_row_blocks_row_split_settings(monkeypatch, split, T, S, R, B):
     check_ops_against_oracle(ctx, case, tol=1e-7 if T == 26 else 1e-9)
     check_steps_against_oracle(ctx, case, np.where(np.arange(B) % 2 == 0, 0.02, -0.02), n_steps=2)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("noisy,gaussian", [(True, False), (False, False), (True, True)])
+def test_momentum_correction_inside_the_jp_pass_is_bitwise_the_separate_pass(monkeypatch, noisy, gaussian):
+    """The momentum correction p -= dh2_flow_mom_dmom @ (mu / dt) and pg <- dh1_dpos of a step (mici _step_b,
+    sde/mici_extensions.py:1233-1238) ride in the J p pass over the compact rows (k_jw_pb<.., FIX>; the u, v_0 and
+    observation-noise columns by KMomFixEdges) -- against CHMC_NO_FIX_IN_JW=1, the separate pass KMomFixInitPg: positions,
+    momenta, statuses, counts and Hamiltonians bitwise equal over 3 steps in both partitions, with masked and failing chains."""
+    B = 37
+    case = make_case("fhn", 10, 16, 5, noisy, B=B, seed=44, gaussian=gaussian)
+    rng = np.random.default_rng(4)
+    qq, xx = np.repeat(case["q"][:1], B, 0), np.repeat(case["x_obs"][:1], B, 0)
+    p = rng.standard_normal(qq.shape)
+    dts = np.where(np.arange(B) % 2 == 0, 1.0, -1.0) * (0.01 + 0.04 * rng.random(B))
+    dts[5] = 5.0
+    act = np.ones(B, dtype=np.int32)
+    act[[2, B - 1]] = 0
+    for part in (0, 1):
+        out = []
+        for off in (None, "1"):
+            if off:
+                monkeypatch.setenv("CHMC_NO_FIX_IN_JW", off)
+            else:
+                monkeypatch.delenv("CHMC_NO_FIX_IN_JW", raising=False)
+            ctx = make_ctx(case)
+            ctx.set_state(qq, p, xx, part)
+            ctx.project_onto_cotangent_space()
+            res = [ctx.leapfrog_step(dts, active=act if k == 0 else None, max_iters=15) for k in range(3)]
+            res.append(ctx.leapfrog_steps(np.abs(dts), 3, active=act, max_iters=15))  # (with the fused kicks of a trajectory)
+            q1, p1, _, _ = ctx.get_state()
+            out.append((res, q1, p1, ctx.hamiltonian()))
+            ctx.close()
+        (ra, qa, pa, ha), (rb, qb, pb, hb) = out
+        for x, y in zip(ra, rb):
+            for k in x:
+                np.testing.assert_array_equal(x[k], y[k], err_msg=k)
+        np.testing.assert_array_equal(qa, qb)
+        np.testing.assert_array_equal(pa, pb)
+        np.testing.assert_array_equal(ha, hb)
+        assert ra[0]["status"][5] > 0 and (ra[0]["status"][[2, B - 1]] == -1).all() and (ra[0]["status"] == 0).sum() > B // 2
+        assert (ra[2]["status"] == 0).sum() > B // 2 and (ra[3]["n_done"] == 3).sum() > B // 2
