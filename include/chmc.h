@@ -205,7 +205,8 @@ int chmc_switch_partition(chmc_ctx* ctx);
  *   CHMC_HALVES=2           two overlapped half-batches per step
  *   read at every call:
  *   CHMC_NO_FWD_SCAN=1      generic functor instead of the hand-scheduled forward scan
- *   CHMC_NO_FIX_IN_JW=1     the momentum correction of a step as its own pass instead of inside the J p pass (same bits)
+ *   CHMC_STEP_FUSIONS=0     the momentum correction and the reverse flow of a step as passes of their own instead of inside
+ *                           the J p / J^T lambda passes (same bits)
  *   CHMC_RETRACT_KERNEL=0/1/2  one 16-row block per chain: batched launches / one workgroup of 8 wavefronts per chain / of 4
  *                           wavefronts (two chains per compute unit).  Default: 8 up to one chain per compute unit, 4 up to
  *                           four, batched beyond; all three give the same bits */

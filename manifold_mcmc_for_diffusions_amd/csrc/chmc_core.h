@@ -1642,7 +1642,22 @@ struct KUpdatePB {  // NS: consecutive steps per work item (2 when S is even: bo
   Work w;
   int which, qsel, psel;
   CheckArgs chk;
+  // TGT 3 with flow_rev: the reverse flow of the step's reversibility check (KFlow{1, 1, 0, -1}: work.qb = h2_flow(q, p, -dt))
+  // for the columns of this pass, from the momentum it has just projected (the u-part: a KFlow launch over U columns;
+  // standard splitting only)
+  int flow_rev = 0;
   CHMC_HD bool has_finish() const { return TGT == 0 && chk.do_check != 0; }
+  CHMC_HD void rev_flow2(int c, int s, size_t i, double px, double py) const {  // KFlow's expressions, a 16-byte pair
+    const double2_ q0 = ld2_stream(pick(sl.q, s) + i);
+    const double dt = -1.0 * w.dt[c];
+    double2_ qn;
+    qn.x = q0.x + dt * px, qn.y = q0.y + dt * py;
+    stv2(w.qb + i, qn, true, true);
+  }
+  CHMC_HD void rev_flow1(int c, int s, size_t i, double px) const {  // ... one component
+    const double dt = -1.0 * w.dt[c];
+    w.qb[i] = pick(sl.q, s)[i] + dt * px;
+  }
   CHMC_HD unsigned* ticket(int c) const { return w.ticket + c; }
   CHMC_HD void finish(int c, unsigned long long ndq_bits) const {
     w.ticket[c] = 0u;
@@ -1745,12 +1760,16 @@ struct KUpdatePB {  // NS: consecutive steps per work item (2 when S is even: bo
           if (TGT == 3) {
             o.x = old2[e * V], o.y = old2[e * V + V - 1];
             *reinterpret_cast<double2_*>(tgt2 + to + e * V) = o;
+            if (flow_rev) rev_flow2(c, s, off + to + e * V, o.x, o.y);
           }
         } else {
           CHMC_UNROLL
           for (int k = 0; k < V; ++k) {
             tgt[to + e * V + k] = old[e * V + k];
-            if (TGT == 3) tgt2[to + e * V + k] = old2[e * V + k];
+            if (TGT == 3) {
+              tgt2[to + e * V + k] = old2[e * V + k];
+              if (flow_rev) rev_flow1(c, s, off + to + e * V + k, old2[e * V + k]);
+            }
           }
         }
       }
@@ -1784,7 +1803,11 @@ struct KUpdatePB {  // NS: consecutive steps per work item (2 when S is even: bo
       }
       if (TGT == 0) r = absbits(d);
       tgt[col] -= d;
-      if (TGT == 3) tgt2[col] -= d2;
+      if (TGT == 3) {
+        const double pn = tgt2[col] - d2;
+        tgt2[col] = pn;
+        if (flow_rev) rev_flow1(c, s, off + col, pn);
+      }
     }
     return r;
   }

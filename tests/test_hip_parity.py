@@ -1061,7 +1061,8 @@ def test_sixteen_row_blocks_row_split_settings(monkeypatch, split, T, S, R, B):
 def test_momentum_correction_inside_the_jp_pass_is_bitwise_the_separate_pass(monkeypatch, noisy, gaussian):
     """The momentum correction p -= dh2_flow_mom_dmom @ (mu / dt) and pg <- dh1_dpos of a step (mici _step_b,
     sde/mici_extensions.py:1233-1238) ride in the J p pass over the compact rows (k_jw_pb<.., FIX>; the u, v_0 and
-    observation-noise columns by KMomFixEdges) -- against CHMC_NO_FIX_IN_JW=1, the separate pass KMomFixInitPg: positions,
+    observation-noise columns by KMomFixEdges), and the reverse flow of the reversibility check rides in the J^T lambda pass
+    (KUpdatePB<.., 3> with flow_rev) -- against CHMC_STEP_FUSIONS=0, the separate passes KMomFixInitPg and KFlow: positions,
     momenta, statuses, counts and Hamiltonians bitwise equal over 3 steps in both partitions, with masked and failing chains."""
     B = 37
     case = make_case("fhn", 10, 16, 5, noisy, B=B, seed=44, gaussian=gaussian)
@@ -1076,9 +1077,9 @@ def test_momentum_correction_inside_the_jp_pass_is_bitwise_the_separate_pass(mon
         out = []
         for off in (None, "1"):
             if off:
-                monkeypatch.setenv("CHMC_NO_FIX_IN_JW", off)
+                monkeypatch.setenv("CHMC_STEP_FUSIONS", "0")
             else:
-                monkeypatch.delenv("CHMC_NO_FIX_IN_JW", raising=False)
+                monkeypatch.delenv("CHMC_STEP_FUSIONS", raising=False)
             ctx = make_ctx(case)
             ctx.set_state(qq, p, xx, part)
             ctx.project_onto_cotangent_space()
