@@ -1463,6 +1463,9 @@ __device__ __forceinline__ void newton_comb_body(const Sys& sy, const Slots& sl,
   for (int e = lane; e < RM * RM; e += 64) Dl[e] = 0.0;
   for (int e = lane; e < RM * Z; e += 64) zl[e] = 0.0;
   lds_sync();
+  // (measured, round 4: staging the interval matrices, the previous point's frames and the observation gradients of ALL
+  // intervals in LDS before this walk does not shorten the launch -- 9.9 -> 10.2 us: with 20 wavefronts per CU the walk's
+  // round trips are hidden, unlike in the one-wavefront-per-chain kernels)
   for (int m = bd.nobs - 1; m >= 0; --m) {
     // rows that start at the end of observation interval m
     if (m < bd.ny) {
@@ -4430,17 +4433,36 @@ __global__ void __launch_bounds__(64) k_newton_fsm_wave(Sys sy, Slots sl, Work w
     const BlockDesc bd = sy.blk[lane];
     const double* lfb = pick(sl.LF, sp) + cb * sy.NOBS * RM * X;
     double* mo = w.muF + cb * sy.NOBS * X;
-    for (int m = 0; m < sy.NOBS; ++m) {
+    // (four intervals at a time, their frames requested together and the results stored afterwards: interval by interval the
+    // run-time loop pays a memory round trip each on the one wavefront of the chain, and this kernel is pure latency)
+    for (int m0 = 0; m0 < sy.NOBS; m0 += 4) {
+      double t4[4][X], lf[4][RM * X];
 #pragma unroll
-      for (int a = 0; a < X; ++a) {
-        double t = 0.0;
-        if (m < bd.nobs) {
+      for (int k = 0; k < 4; ++k) {  // (the loads under wave-uniform conditions only: all of them issue before the first use)
+        const bool in = m0 + k < sy.NOBS;
 #pragma unroll
-          for (int i = 0; i < RM; ++i)
-            if (i < bd.nrows) t += lam[i] * lfb[(m * RM + i) * X + a];
-        }
-        mo[m * X + a] = t;
+        for (int e = 0; e < RM * X; ++e) lf[k][e] = in ? lfb[(m0 + k) * RM * X + e] : 0.0;
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int m = m0 + k;
+#pragma unroll
+        for (int a = 0; a < X; ++a) {
+          double t = 0.0;
+          if (m < bd.nobs) {
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+              if (i < bd.nrows) t += lam[i] * lf[k][i * X + a];
+          }
+          t4[k][a] = t;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (m0 + k < sy.NOBS) {
+#pragma unroll
+          for (int a = 0; a < X; ++a) mo[(m0 + k) * X + a] = t4[k][a];
+        }
     }
   }
 }
