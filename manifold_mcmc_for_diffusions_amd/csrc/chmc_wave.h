@@ -4584,22 +4584,50 @@ __global__ void __launch_bounds__(64) k_xobs_par(Sys sy, Slots sl, double* xobs_
     for (int a = 0; a < X; ++a) x[a] = Ul[a];
 #pragma unroll
     for (int i = 0; i < X * X; ++i) P[i] = (i / X == i % X) ? 1.0 : 0.0;
-    for (int s = s0; s < s1; ++s) {
-      double vv[V], A[X * X], Bm[X * V], xn[X], Pn[X * X];
+    // The noise increments of the NEXT eight steps are requested before the current eight are integrated: a step of this
+    // loop is about 40 ns of arithmetic (FitzHugh-Nagumo) behind a load whose latency is ten times that, and the chain has
+    // this one wavefront -- 626 us per partition switch at configs[1] with a load per step in the loop.  (Addresses past the
+    // segment are clamped to its last step; those values are not used.)
+    constexpr int CH = 8;
+    double vb[2][CH * V];
+    auto fetch = [&](int base, double* dst) {
 #pragma unroll
-      for (int a = 0; a < V; ++a) vv[a] = vbase[(size_t)s * V + a];
-      M::jac_ab(cc.k, x, vv, A, Bm);
-      M::step(cc.k, x, vv, xn);
-      matmul_xx<X>(A, P, Pn);
+      for (int j = 0; j < CH; ++j) {
+        int sj = base + j;
+        sj = sj < L ? sj : L - 1;
 #pragma unroll
-      for (int i = 0; i < X * X; ++i) P[i] = Pn[i];
-#pragma unroll
-      for (int a = 0; a < X; ++a) x[a] = xn[a];
-      if ((s + 1) % S == 0) {
-        const int t = (s + 1) / S - 1;
-#pragma unroll
-        for (int a = 0; a < X; ++a) out[t * X + a] = x[a];
+        for (int a = 0; a < V; ++a) dst[j * V + a] = vbase[(size_t)sj * V + a];
       }
+    };
+    auto run = [&](int base, const double* src) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int s = base + j;
+        if (s < s1) {
+          double vv[V], A[X * X], Bm[X * V], xn[X], Pn[X * X];
+#pragma unroll
+          for (int a = 0; a < V; ++a) vv[a] = src[j * V + a];
+          M::jac_ab(cc.k, x, vv, A, Bm);
+          M::step(cc.k, x, vv, xn);
+          matmul_xx<X>(A, P, Pn);
+#pragma unroll
+          for (int i = 0; i < X * X; ++i) P[i] = Pn[i];
+#pragma unroll
+          for (int a = 0; a < X; ++a) x[a] = xn[a];
+          if ((s + 1) % S == 0) {
+            const int t = (s + 1) / S - 1;
+#pragma unroll
+            for (int a = 0; a < X; ++a) out[t * X + a] = x[a];
+          }
+        }
+      }
+    };
+    if (have) fetch(s0, vb[0]);
+    for (int base = s0; base < s1; base += 2 * CH) {  // (two chunks per trip: the buffers are indexed statically)
+      fetch(base + CH, vb[1]);
+      run(base, vb[0]);
+      fetch(base + 2 * CH, vb[0]);
+      run(base + CH, vb[1]);
     }
     double ec[X], Pc[X * X], Unext[X];
 #pragma unroll
