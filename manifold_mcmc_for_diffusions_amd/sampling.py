@@ -142,16 +142,13 @@ def sample_static_chmc(ctx, n_iter, n_step, step_size, seed, chain_offset=0, n_a
         scale = 0.5 ** np.minimum(stuck, 8) if it < n_adapt else 1.0
         dt = np.where(draw() < 0.5, step_size, -step_size) * scale
         act = np.ones(B, dtype=np.int32)
-        length = 1 + np.floor(draw() * n_step).astype(np.int64) if jitter_length else np.full(B, n_step)
-        end_status = np.zeros(B, dtype=np.int64)
-        for k in range(n_step):
-            run = (act == 1) & (k < length)
-            if not run.any():
-                break
-            r = ctx.leapfrog_step(dt, active=run.astype(np.int32), **solver)
-            bad = run & (r["status"] != 0)
-            end_status = np.where(bad, r["status"], end_status)
-            act &= (~bad).astype(np.int32)
+        # the trajectory as ONE library call (the loop an integration transition runs around integrator.step,
+        # scripts/utils.py:284-301: a chain stops at its first failed step): single-block layouts walk it in one launch per
+        # chain, the lock-step path folds the kicks of consecutive steps when every chain takes the same number of steps
+        length = 1 + np.floor(draw() * n_step).astype(np.int32) if jitter_length else int(n_step)
+        r = ctx.leapfrog_steps(dt, length, active=act, **solver)
+        end_status = np.where(r["status"] > 0, r["status"], 0).astype(np.int64)
+        act &= (r["status"] == 0).astype(np.int32)
         h1 = ctx.hamiltonian()[:, 0]
         dh = h1 - h0
         prob = np.where((act == 1) & np.isfinite(dh), np.exp(np.minimum(0.0, -np.where(np.isfinite(dh), dh, np.inf))), 0.0)
