@@ -191,7 +191,8 @@ int chmc_switch_partition(chmc_ctx* ctx);
  * rebuild the row-slot array first (one extra pass, only when called); results are the same to rounding.
  *
  * Environment switches -- EVERY variable the library reads; each is exercised by a GPU test.  Defaults are chosen from the
- * layout (blocks per chain, block length, rows) alone, never from the number of chains, so a chain's results do not depend
+ * layout (blocks per chain, block length, rows) alone, never from the number of chains -- the one exception, the execution
+ * model of single-block layouts (CHMC_RETRACT_KERNEL), chooses between bit-identical paths --, so a chain's results do not depend
  * on the shard it runs in (bitwise: tests/test_hip_parity.py::test_results_do_not_depend_on_the_shard_size).  Pinning a
  * switch to a non-default value changes bits at the rounding level (summation order; the time-parallel scan equals the
  * sequential recursion to about 1e-15 relative after its final sweep, not bitwise), never statuses.
